@@ -1,0 +1,876 @@
+// C ABI of libcddpm_hip.so (declared in include/cddpm.h): handle, weight packing, embedding tables,
+// the UNet forward program and the reverse-diffusion loop driver. Host code only; kernels live in
+// conv_mfma.hip, norm_kernels.hip, small_kernels.hip and attention.hip.
+//
+// Data layout in HBM: every activation is NHWC fp32 ([B][H*W][C], 16-B aligned channel quads); the image
+// itself has one channel, so the [B,1,H,W] boundary tensors need no conversion. Skip-stack tensors, three
+// ping-pong activation buffers, the qkv/attention buffers, GroupNorm partials and coefficient planes, the
+// packed weights and the [T][sumE] time-embedding table are allocated once in cddpm_create.
+#include "../../include/cddpm.h"
+#include "kernels.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+using namespace cddpm;
+
+namespace {
+
+struct ConvW { float* wpk = nullptr; float* bias = nullptr; int Cin = 0, Cout = 0, taps = 0; };
+struct NormW { float* gamma = nullptr; float* beta = nullptr; int C = 0; };
+
+struct ResW {
+    std::string prefix;
+    int Cin = 0, Cout = 0;
+    bool up = false, down = false, has_skip = false;
+    NormW gn1, gn2;
+    ConvW conv1, conv2, skip;
+    float* bias2 = nullptr;   // conv2 bias (+ skip_connection bias when has_skip)
+    int eoff = 0;             // offset of this block's (scale | shift) slice in the sumE-wide tables
+};
+struct AttnW {
+    std::string prefix;
+    int C = 0;
+    NormW norm;
+    ConvW qkv, proj;
+};
+
+enum OpKind { OP_IN = 0, OP_RES = 1, OP_ATTN = 2, OP_HEAD = 3 };
+struct Op {
+    OpKind kind;
+    int idx;          // index into res / attn
+    bool concat;      // pop the skip stack and concatenate before this op (output path)
+    bool push;        // push the result on the skip stack (input path)
+    bool block_end;   // last op of a named block: tap point
+    int block;        // block ordinal
+};
+struct BlockInfo { std::string name; int C; int ds; };
+
+struct WeightSpec { std::string name; int64_t numel; };
+
+thread_local std::string g_create_error;
+
+}  // namespace
+
+struct cddpm_ctx {
+    cddpm_unet_desc d;
+    int device = 0;
+    std::string err;
+    bool weights_loaded = false, schedule_set = false;
+    int cond_B = -1;
+
+    std::vector<ResW> res;
+    std::vector<AttnW> attn;
+    std::vector<Op> prog;
+    std::vector<BlockInfo> blocks;
+    std::vector<float*> taps;
+    std::vector<WeightSpec> wspecs;
+    std::vector<void*> allocs;
+    size_t alloc_bytes = 0;
+
+    // in / head convs, embedding MLPs
+    float *in_w = nullptr, *in_b = nullptr;        // [C][9], [C]
+    NormW out_norm;
+    float* head_w9 = nullptr;                      // [9][C]
+    float head_bias = 0.f;
+    float *te0_w = nullptr, *te0_b = nullptr, *te2_w = nullptr, *te2_b = nullptr;
+    float *le0_w = nullptr, *le0_b = nullptr, *le2_w = nullptr, *le2_b = nullptr;
+    float *emb_w = nullptr, *emb_b = nullptr;      // [sumE][E], [sumE]
+    int sumE = 0, E = 0, half = 0;
+
+    // tables
+    float *tab = nullptr, *cpart = nullptr;        // [T][sumE], [Bmax][sumE]
+    float *sched[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // coef1, coef2, logvar, sqrt_recip, sqrt_recipm1
+    float *qs_sa = nullptr, *qs_s1 = nullptr;
+    int objective = 0;
+    int* d_t = nullptr;
+
+    // workspace
+    std::vector<float*> hs;                        // skip stack tensors (input path outputs)
+    std::vector<size_t> hs_elems;
+    float *bufA = nullptr, *bufB = nullptr, *bufH = nullptr, *bufP0 = nullptr, *bufP1 = nullptr;
+    float *qkvbuf = nullptr, *attbuf = nullptr, *headP = nullptr, *model_out = nullptr;
+    double* gn_part = nullptr;
+    float* coef = nullptr;
+    float *scratch0 = nullptr, *scratch1 = nullptr;   // [max(T,Bmax)][half] for the embedding MLPs
+    int max_nsplit = 0;
+};
+
+namespace {
+
+int fail(cddpm_ctx* h, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (h) h->err = buf; else g_create_error = buf;
+    return -1;
+}
+
+#define HIPCHECK(h, call)                                                                      \
+    do {                                                                                       \
+        hipError_t e_ = (call);                                                                \
+        if (e_ != hipSuccess) return fail(h, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+template <typename T>
+int dev_alloc(cddpm_ctx* h, T** p, size_t count) {
+    void* q = nullptr;
+    const size_t bytes = (count ? count : 1) * sizeof(T);
+    hipError_t e = hipMalloc(&q, bytes);
+    if (e != hipSuccess) return fail(h, "hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+    h->allocs.push_back(q);
+    h->alloc_bytes += bytes;
+    *p = reinterpret_cast<T*>(q);
+    return 0;
+}
+
+bool in_list(const int* v, int n, int x) {
+    for (int i = 0; i < n; ++i) if (v[i] == x) return true;
+    return false;
+}
+
+int validate_desc(cddpm_ctx* h, const cddpm_unet_desc* d) {
+    if (!d) return fail(h, "descriptor is NULL");
+    if (d->in_channels != 1 || d->out_channels != 1)
+        return fail(h, "in_channels/out_channels must be 1 (got %d/%d)", d->in_channels, d->out_channels);
+    if (d->model_channels <= 0 || d->model_channels % 128 != 0 || d->model_channels > 512)
+        return fail(h, "model_channels must be 128, 256, 384 or 512 (MFMA tile N = 128), got %d", d->model_channels);
+    if (d->num_levels < 1 || d->num_levels > CDDPM_MAX_LEVELS) return fail(h, "num_levels out of range: %d", d->num_levels);
+    for (int i = 0; i < d->num_levels; ++i)
+        if (d->channel_mult[i] < 1 || d->channel_mult[i] * d->model_channels > 1024)
+            return fail(h, "channel_mult[%d]=%d unsupported", i, d->channel_mult[i]);
+    if (d->num_res_blocks < 1) return fail(h, "num_res_blocks must be >= 1");
+    if (d->num_attention_resolutions < 0 || d->num_attention_resolutions > CDDPM_MAX_LEVELS)
+        return fail(h, "num_attention_resolutions out of range");
+    if (d->head_channels != 64) return fail(h, "head_channels must be 64, got %d", d->head_channels);
+    if (d->cond_dim < 0 || d->cond_dim % 4 != 0) return fail(h, "cond_dim must be a non-negative multiple of 4");
+    if (d->timesteps < 1) return fail(h, "timesteps must be >= 1");
+    const int q = 1 << (d->num_levels - 1);
+    if (d->max_batch < 1 || d->max_h < q || d->max_w < q || d->max_h % q || d->max_w % q || d->max_h % 4 || d->max_w % 4)
+        return fail(h, "max_batch/max_h/max_w invalid (H, W must be multiples of %d and of 4)", q > 4 ? q : 4);
+    return 0;
+}
+
+// ---- program construction: mirrors UNetModel.__init__ (src/models/modules/OpenAI_Unet.py:604-797)
+void add_norm_spec(cddpm_ctx* h, const std::string& p, int C) {
+    h->wspecs.push_back({p + ".weight", C});
+    h->wspecs.push_back({p + ".bias", C});
+}
+void add_conv_spec(cddpm_ctx* h, const std::string& p, int Cin, int Cout, int k) {
+    h->wspecs.push_back({p + ".weight", (int64_t)Cout * Cin * k});
+    h->wspecs.push_back({p + ".bias", Cout});
+}
+
+int make_res(cddpm_ctx* h, const std::string& prefix, int Cin, int Cout, bool up, bool down) {
+    ResW r;
+    r.prefix = prefix; r.Cin = Cin; r.Cout = Cout; r.up = up; r.down = down; r.has_skip = (Cin != Cout);
+    r.eoff = h->sumE;
+    h->sumE += 2 * Cout;
+    add_norm_spec(h, prefix + ".in_layers.0", Cin);
+    add_conv_spec(h, prefix + ".in_layers.2", Cin, Cout, 9);
+    h->wspecs.push_back({prefix + ".emb_layers.1.weight", (int64_t)2 * Cout * h->E});
+    h->wspecs.push_back({prefix + ".emb_layers.1.bias", 2 * Cout});
+    add_norm_spec(h, prefix + ".out_layers.0", Cout);
+    add_conv_spec(h, prefix + ".out_layers.3", Cout, Cout, 9);
+    if (r.has_skip) add_conv_spec(h, prefix + ".skip_connection", Cin, Cout, 1);
+    h->res.push_back(r);
+    return (int)h->res.size() - 1;
+}
+int make_attn(cddpm_ctx* h, const std::string& prefix, int C) {
+    AttnW a;
+    a.prefix = prefix; a.C = C;
+    add_norm_spec(h, prefix + ".norm", C);
+    add_conv_spec(h, prefix + ".qkv", C, 3 * C, 1);
+    add_conv_spec(h, prefix + ".proj_out", C, C, 1);
+    h->attn.push_back(a);
+    return (int)h->attn.size() - 1;
+}
+
+void build_program(cddpm_ctx* h) {
+    const cddpm_unet_desc& d = h->d;
+    const int C = d.model_channels;
+    h->half = 4 * C;
+    h->E = d.cond_dim > 0 ? 2 * h->half : h->half;
+    if (d.cond_dim > 0) {
+        h->wspecs.push_back({"label_emb.0.weight", (int64_t)h->half * d.cond_dim});
+        h->wspecs.push_back({"label_emb.0.bias", h->half});
+        h->wspecs.push_back({"label_emb.2.weight", (int64_t)h->half * h->half});
+        h->wspecs.push_back({"label_emb.2.bias", h->half});
+    }
+    h->wspecs.push_back({"time_embed.0.weight", (int64_t)h->half * C});
+    h->wspecs.push_back({"time_embed.0.bias", h->half});
+    h->wspecs.push_back({"time_embed.2.weight", (int64_t)h->half * h->half});
+    h->wspecs.push_back({"time_embed.2.bias", h->half});
+    add_conv_spec(h, "input_blocks.0.0", 1, C, 9);
+
+    auto new_block = [&](const std::string& name, int Cb, int ds) {
+        h->blocks.push_back({name, Cb, ds});
+        return (int)h->blocks.size() - 1;
+    };
+    std::vector<int> chans;
+    int ch = C, ds = 1, idx = 1;
+    int blk = new_block("input_blocks.0", C, 1);
+    h->prog.push_back({OP_IN, 0, false, true, true, blk});
+    chans.push_back(C);
+    for (int level = 0; level < d.num_levels; ++level) {
+        const int co = d.channel_mult[level] * C;
+        for (int i = 0; i < d.num_res_blocks; ++i) {
+            const std::string bn = "input_blocks." + std::to_string(idx);
+            const bool at = in_list(d.attention_resolutions, d.num_attention_resolutions, ds);
+            blk = new_block(bn, co, ds);
+            h->prog.push_back({OP_RES, make_res(h, bn + ".0", ch, co, false, false), false, !at, !at, blk});
+            ch = co;
+            if (at) h->prog.push_back({OP_ATTN, make_attn(h, bn + ".1", ch), false, true, true, blk});
+            chans.push_back(ch);
+            ++idx;
+        }
+        if (level != d.num_levels - 1) {
+            const std::string bn = "input_blocks." + std::to_string(idx);
+            ds *= 2;
+            blk = new_block(bn, ch, ds);
+            h->prog.push_back({OP_RES, make_res(h, bn + ".0", ch, ch, false, true), false, true, true, blk});
+            chans.push_back(ch);
+            ++idx;
+        }
+    }
+    blk = new_block("middle_block.0", ch, ds);
+    h->prog.push_back({OP_RES, make_res(h, "middle_block.0", ch, ch, false, false), false, false, true, blk});
+    blk = new_block("middle_block.1", ch, ds);
+    h->prog.push_back({OP_ATTN, make_attn(h, "middle_block.1", ch), false, false, true, blk});
+    blk = new_block("middle_block.2", ch, ds);
+    h->prog.push_back({OP_RES, make_res(h, "middle_block.2", ch, ch, false, false), false, false, true, blk});
+    idx = 0;
+    for (int level = d.num_levels - 1; level >= 0; --level) {
+        const int co = d.channel_mult[level] * C;
+        for (int i = 0; i <= d.num_res_blocks; ++i) {
+            const int ich = chans.back();
+            chans.pop_back();
+            const std::string bn = "output_blocks." + std::to_string(idx);
+            const bool at = in_list(d.attention_resolutions, d.num_attention_resolutions, ds);
+            const bool upb = (level > 0 && i == d.num_res_blocks);
+            const int ds_out = upb ? ds / 2 : ds;
+            blk = new_block(bn, co, ds_out);
+            h->prog.push_back({OP_RES, make_res(h, bn + ".0", ch + ich, co, false, false), true, false, !at && !upb, blk});
+            ch = co;
+            int sub = 1;
+            if (at) {
+                h->prog.push_back({OP_ATTN, make_attn(h, bn + "." + std::to_string(sub), ch), false, false, !upb, blk});
+                ++sub;
+            }
+            if (upb) {
+                h->prog.push_back({OP_RES, make_res(h, bn + "." + std::to_string(sub), ch, ch, true, false), false, false, true, blk});
+                ds /= 2;
+            }
+            ++idx;
+        }
+    }
+    add_norm_spec(h, "out.0", ch);
+    add_conv_spec(h, "out.2", ch, 1, 9);
+    blk = new_block("out", 1, 1);
+    h->prog.push_back({OP_HEAD, 0, false, false, true, blk});
+    h->taps.assign(h->blocks.size(), nullptr);
+}
+
+size_t plan_workspace(cddpm_ctx* h, bool do_alloc, int* rc) {
+    // returns the byte count; allocates when do_alloc
+    const cddpm_unet_desc& d = h->d;
+    const size_t B = d.max_batch, HW = (size_t)d.max_h * d.max_w;
+    size_t total = 0;
+    *rc = 0;
+    auto want = [&](float** p, size_t elems) {
+        total += elems * sizeof(float);
+        if (do_alloc && *rc == 0) *rc = dev_alloc(h, p, elems);
+    };
+    // skip stack: one tensor per pushing op
+    size_t maxact = 0, maxC = 0;
+    h->hs.clear();
+    h->hs_elems.clear();
+    for (const Op& op : h->prog) {
+        const BlockInfo& bi = h->blocks[op.block];
+        const size_t elems = B * (HW / ((size_t)bi.ds * bi.ds)) * bi.C;
+        if (op.kind != OP_HEAD) maxact = std::max(maxact, elems);
+        if (op.push) {
+            float* p = nullptr;
+            want(&p, elems);
+            h->hs.push_back(p);
+            h->hs_elems.push_back(elems);
+        }
+    }
+    for (const ResW& r : h->res) {
+        maxC = std::max(maxC, (size_t)std::max(r.Cin, r.Cout));
+        if (r.up) {   // conv1 output of an up block lives at the doubled resolution
+            // covered by maxact through the block's own output size (same C, same resolution)
+        }
+    }
+    for (const AttnW& a : h->attn) maxC = std::max(maxC, (size_t)a.C);
+    want(&h->bufA, maxact);
+    want(&h->bufB, maxact);
+    want(&h->bufH, maxact);
+    want(&h->bufP0, maxact / 4 + 16);
+    want(&h->bufP1, maxact / 4 + 16);
+    size_t maxqkv = 0, maxatt = 0;
+    for (const Op& op : h->prog)
+        if (op.kind == OP_ATTN) {
+            const BlockInfo& bi = h->blocks[op.block];
+            const AttnW& a = h->attn[op.idx];
+            // an attention op inside an up block runs before the upsample: resolution of the block input
+            int dsa = bi.ds;
+            for (const Op& o2 : h->prog)
+                if (o2.block == op.block && o2.kind == OP_RES && h->res[o2.idx].up) dsa = bi.ds * 2;
+            const size_t n = HW / ((size_t)dsa * dsa);
+            maxqkv = std::max(maxqkv, B * n * 3 * a.C);
+            maxatt = std::max(maxatt, B * n * a.C);
+        }
+    want(&h->qkvbuf, maxqkv);
+    want(&h->attbuf, maxatt);
+    want(&h->headP, B * HW * 9);
+    want(&h->model_out, B * HW);
+    size_t max_rec = 1;   // max over B' <= max_batch of B' * nsplit(B'): records of one GroupNorm sweep
+    for (int b = 1; b <= d.max_batch; ++b) max_rec = std::max(max_rec, (size_t)b * gn_nsplit(b, (int)HW));
+    h->max_nsplit = gn_nsplit(1, (int)HW);
+    {
+        const size_t elems = max_rec * maxC * 2;
+        total += elems * sizeof(double);
+        if (do_alloc && *rc == 0) *rc = dev_alloc(h, &h->gn_part, elems);
+    }
+    want(&h->coef, 3 * B * maxC);
+    // tables and embedding scratch
+    const size_t rows = std::max<size_t>(d.timesteps, B);
+    want(&h->tab, (size_t)d.timesteps * h->sumE);
+    want(&h->cpart, B * (size_t)h->sumE);
+    want(&h->scratch0, rows * std::max(h->half, d.model_channels));
+    want(&h->scratch1, rows * h->half);
+    for (int i = 0; i < 5; ++i) want(&h->sched[i], d.timesteps);
+    want(&h->qs_sa, d.timesteps);
+    want(&h->qs_s1, d.timesteps);
+    total += B * sizeof(int);
+    if (do_alloc && *rc == 0) *rc = dev_alloc(h, &h->d_t, B);
+    // weights
+    for (const WeightSpec& w : h->wspecs) total += (size_t)w.numel * sizeof(float);
+    total += (size_t)h->sumE * sizeof(float);   // combined emb bias is part of wspecs already; slack
+    return total;
+}
+
+struct HostWeights {
+    std::map<std::string, std::pair<const float*, int64_t>> m;
+    const float* get(const std::string& n) const { return m.at(n).first; }
+};
+
+int upload(cddpm_ctx* h, float** dst, const float* src, size_t n) {
+    if (dev_alloc(h, dst, n)) return -1;
+    HIPCHECK(h, hipMemcpy(*dst, src, n * sizeof(float), hipMemcpyHostToDevice));
+    return 0;
+}
+
+int upload_norm(cddpm_ctx* h, const HostWeights& hw, const std::string& p, int C, NormW* n) {
+    n->C = C;
+    if (upload(h, &n->gamma, hw.get(p + ".weight"), C)) return -1;
+    return upload(h, &n->beta, hw.get(p + ".bias"), C);
+}
+
+int upload_conv(cddpm_ctx* h, const HostWeights& hw, const std::string& p, int Cin, int Cout, int taps, ConvW* c,
+                bool with_bias = true) {
+    c->Cin = Cin; c->Cout = Cout; c->taps = taps;
+    std::vector<float> pk(packed_conv_floats(Cout, Cin, taps));
+    pack_conv_weights(hw.get(p + ".weight"), Cout, Cin, taps, pk.data());
+    if (upload(h, &c->wpk, pk.data(), pk.size())) return -1;
+    if (with_bias) return upload(h, &c->bias, hw.get(p + ".bias"), Cout);
+    return 0;
+}
+
+void gn_coef(cddpm_ctx* h, const float* x0, int C0, const float* x1, int C1, int B, int HW, const NormW& nw,
+             bool film, int eoff, hipStream_t s) {
+    const int Ct = C0 + C1;
+    const int ns = gn_nsplit(B, HW);
+    launch_gn_partial(x0, C0, Ct, 0, B, HW, ns, h->gn_part, s);
+    if (x1) launch_gn_partial(x1, C1, Ct, C0, B, HW, ns, h->gn_part, s);
+    launch_gn_finalize(h->gn_part, ns, Ct, B, HW, nw.gamma, nw.beta, film ? h->tab : nullptr, h->cpart, h->sumE, eoff,
+                       h->d_t, nullptr, h->coef, s);
+}
+
+void zero_conv_args(ConvArgs& a) { memset(&a, 0, sizeof a); }
+
+// One ResBlock (src/models/modules/OpenAI_Unet.py:284-338): input x0 (+ x1 concatenated), output dst.
+void run_res(cddpm_ctx* h, const ResW& r, const float* x0, int C0, const float* x1, int C1, float* dst, int B, int H,
+             int W, hipStream_t s) {
+    // H, W: resolution of the block INPUT
+    gn_coef(h, x0, C0, x1, C1, B, H * W, r.gn1, false, 0, s);
+    ConvArgs a;
+    zero_conv_args(a);
+    a.B = B; a.Cout = r.Cout; a.taps = 9; a.wpk = r.conv1.wpk; a.bias = r.conv1.bias; a.out = h->bufH;
+    int Ho = H, Wo = W;
+    const float* resid = x0;
+    int res_up = 0;
+    if (r.down) {
+        Ho = H / 2; Wo = W / 2;
+        launch_pool_act(x0, h->coef, h->bufP0, h->bufP1, B, H, W, C0, s);
+        a.src0 = h->bufP0; a.C0 = C0; a.srcH = Ho; a.srcW = Wo;
+        resid = h->bufP1;
+    } else if (r.up) {
+        Ho = 2 * H; Wo = 2 * W;
+        a.src0 = x0; a.C0 = C0; a.srcH = H; a.srcW = W; a.upsample = 1; a.coef = h->coef; a.silu = 1;
+        res_up = 1;
+    } else {
+        a.src0 = x0; a.C0 = C0; a.src1 = x1; a.C1 = C1; a.srcH = H; a.srcW = W; a.coef = h->coef; a.silu = 1;
+    }
+    a.H = Ho; a.W = Wo;
+    launch_conv(a, s);
+    // out_layers: GroupNorm * (1 + scale) + shift -> SiLU -> conv, + skip
+    gn_coef(h, h->bufH, r.Cout, nullptr, 0, B, Ho * Wo, r.gn2, true, r.eoff, s);
+    ConvArgs c;
+    zero_conv_args(c);
+    c.B = B; c.H = Ho; c.W = Wo; c.Cout = r.Cout; c.taps = 9;
+    c.src0 = h->bufH; c.C0 = r.Cout; c.srcH = Ho; c.srcW = Wo; c.coef = h->coef; c.silu = 1;
+    c.wpk = r.conv2.wpk; c.bias = r.bias2; c.out = dst;
+    if (r.has_skip) {
+        c.skip0 = x0; c.S0 = C0; c.skip1 = x1; c.S1 = C1; c.skip_wpk = r.skip.wpk;
+    } else {
+        c.res = resid; c.res_up = res_up;
+    }
+    launch_conv(c, s);
+}
+
+// AttentionBlock (OpenAI_Unet.py:386-394)
+void run_attn(cddpm_ctx* h, const AttnW& w, const float* x, float* dst, int B, int H, int W, hipStream_t s) {
+    const int N = H * W;
+    gn_coef(h, x, w.C, nullptr, 0, B, N, w.norm, false, 0, s);
+    ConvArgs a;
+    zero_conv_args(a);
+    a.B = B; a.H = H; a.W = W; a.Cout = 3 * w.C; a.taps = 1;
+    a.src0 = x; a.C0 = w.C; a.srcH = H; a.srcW = W; a.coef = h->coef; a.silu = 0;
+    a.wpk = w.qkv.wpk; a.bias = w.qkv.bias; a.out = h->qkvbuf;
+    launch_conv(a, s);
+    launch_attention(h->qkvbuf, h->attbuf, B, N, w.C, s);
+    ConvArgs p;
+    zero_conv_args(p);
+    p.B = B; p.H = H; p.W = W; p.Cout = w.C; p.taps = 1;
+    p.src0 = h->attbuf; p.C0 = w.C; p.srcH = H; p.srcW = W;
+    p.wpk = w.proj.wpk; p.bias = w.proj.bias; p.res = x; p.out = dst;
+    launch_conv(p, s);
+}
+
+int check_call(cddpm_ctx* h, int B, int H, int W) {
+    if (!h) return -1;
+    if (!h->weights_loaded) return fail(h, "weights not loaded (cddpm_load_weights)");
+    if (!h->schedule_set) return fail(h, "schedule not set (cddpm_set_schedule)");
+    const int q = 1 << (h->d.num_levels - 1);
+    if (B < 1 || B > h->d.max_batch) return fail(h, "B=%d outside [1, max_batch=%d]", B, h->d.max_batch);
+    if (H < q || W < q || H % q || W % q || H % 4 || W % 4 || H > h->d.max_h || W > h->d.max_w ||
+        (size_t)H * W > (size_t)h->d.max_h * h->d.max_w)
+        return fail(h, "H=%d W=%d invalid for this handle (multiples of %d, max %dx%d)", H, W, q > 4 ? q : 4, h->d.max_h, h->d.max_w);
+    if (h->cond_B != B) return fail(h, "cddpm_prepare_cond was last called for B=%d, this call has B=%d", h->cond_B, B);
+    return 0;
+}
+
+// UNetModel.forward (OpenAI_Unet.py:823-1006); d_t must hold the per-sample timesteps.
+int forward_impl(cddpm_ctx* h, const float* x, float* out, int B, int H, int W, hipStream_t s) {
+    std::vector<int> stack;   // indices into h->hs
+    int npush = 0;
+    const float* cur = nullptr;
+    int curC = 0, curds = 1;
+    float* pp[2] = {h->bufA, h->bufB};
+    int ppi = 0;
+    for (size_t oi = 0; oi < h->prog.size(); ++oi) {
+        const Op& op = h->prog[oi];
+        const BlockInfo& bi = h->blocks[op.block];
+        float* dst;
+        if (op.push) dst = h->hs[npush];
+        else { dst = pp[ppi]; ppi ^= 1; }
+        const int Hc = H / curds, Wc = W / curds;
+        switch (op.kind) {
+            case OP_IN:
+                launch_conv_in1(x, h->in_w, h->in_b, dst, B, H, W, h->d.model_channels, s);
+                curC = h->d.model_channels;
+                break;
+            case OP_RES: {
+                const ResW& r = h->res[op.idx];
+                const float* x1 = nullptr;
+                int C1 = 0;
+                if (op.concat) {
+                    const int si = stack.back();
+                    stack.pop_back();
+                    x1 = h->hs[si];
+                    C1 = r.Cin - curC;
+                }
+                if (dst == cur) { dst = pp[ppi]; ppi ^= 1; }
+                run_res(h, r, cur, curC, x1, C1, dst, B, Hc, Wc, s);
+                curC = r.Cout;
+                if (r.down) curds *= 2;
+                if (r.up) curds /= 2;
+                break;
+            }
+            case OP_ATTN:
+                if (dst == cur) { dst = pp[ppi]; ppi ^= 1; }
+                run_attn(h, h->attn[op.idx], cur, dst, B, Hc, Wc, s);
+                break;
+            case OP_HEAD: {
+                gn_coef(h, cur, curC, nullptr, 0, B, H * W, h->out_norm, false, 0, s);
+                launch_head_dots(cur, h->coef, h->head_w9, h->headP, B, H * W, curC, s);
+                launch_head_gather(h->headP, h->head_bias, out, B, H, W, s);
+                dst = nullptr;
+                break;
+            }
+        }
+        if (op.push) { stack.push_back(npush); ++npush; }
+        if (dst) cur = dst;
+        if (op.block_end && dst && h->taps[op.block]) {
+            const size_t elems = (size_t)B * (H / bi.ds) * (W / bi.ds) * bi.C;
+            HIPCHECK(h, hipMemcpyAsync(h->taps[op.block], dst, elems * sizeof(float), hipMemcpyDeviceToDevice, s));
+        }
+    }
+    HIPCHECK(h, hipGetLastError());
+    return 0;
+}
+
+}  // namespace
+
+// ================================================================================================
+// C ABI
+// ================================================================================================
+extern "C" {
+
+const char* cddpm_last_error(cddpm_handle h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+size_t cddpm_workspace_bytes(const cddpm_unet_desc* desc) {
+    cddpm_ctx tmp;
+    if (validate_desc(nullptr, desc)) return 0;
+    tmp.d = *desc;
+    build_program(&tmp);
+    int rc = 0;
+    return plan_workspace(&tmp, false, &rc);
+}
+
+int cddpm_create(cddpm_handle* out, const cddpm_unet_desc* desc, int device) {
+    if (!out) return fail(nullptr, "out is NULL");
+    *out = nullptr;
+    if (validate_desc(nullptr, desc)) return -1;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) return fail(nullptr, "no HIP device available: %s", hipGetErrorString(e));
+    if (device < 0 || device >= ndev) return fail(nullptr, "device %d out of range (%d devices)", device, ndev);
+    e = hipSetDevice(device);
+    if (e != hipSuccess) return fail(nullptr, "hipSetDevice(%d): %s", device, hipGetErrorString(e));
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, device);
+    if (e != hipSuccess) return fail(nullptr, "hipGetDeviceProperties: %s", hipGetErrorString(e));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(nullptr, "device %d is %s; this library is built for gfx950 (MI355X) only", device, prop.gcnArchName);
+    cddpm_ctx* h = new cddpm_ctx();
+    h->d = *desc;
+    h->device = device;
+    build_program(h);
+    int rc = 0;
+    plan_workspace(h, true, &rc);
+    if (rc) {
+        g_create_error = h->err;
+        cddpm_destroy(h);
+        return -1;
+    }
+    *out = h;
+    return 0;
+}
+
+void cddpm_destroy(cddpm_handle h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    for (void* p : h->allocs) (void)hipFree(p);
+    delete h;
+}
+
+int cddpm_num_weights(cddpm_handle h) { return h ? (int)h->wspecs.size() : -1; }
+const char* cddpm_weight_name(cddpm_handle h, int i) {
+    return (h && i >= 0 && i < (int)h->wspecs.size()) ? h->wspecs[i].name.c_str() : nullptr;
+}
+int64_t cddpm_weight_numel(cddpm_handle h, int i) {
+    return (h && i >= 0 && i < (int)h->wspecs.size()) ? h->wspecs[i].numel : -1;
+}
+
+int cddpm_num_blocks(cddpm_handle h) { return h ? (int)h->blocks.size() : -1; }
+const char* cddpm_block_name(cddpm_handle h, int i) {
+    return (h && i >= 0 && i < (int)h->blocks.size()) ? h->blocks[i].name.c_str() : nullptr;
+}
+int cddpm_set_tap(cddpm_handle h, int block, float* dst_dev) {
+    if (!h) return -1;
+    if (block < 0 || block >= (int)h->blocks.size()) return fail(h, "block %d out of range", block);
+    h->taps[block] = dst_dev;
+    return 0;
+}
+int cddpm_block_shape(cddpm_handle h, int block, int H, int W, int* C, int* h_out, int* w_out) {
+    if (!h) return -1;
+    if (block < 0 || block >= (int)h->blocks.size()) return fail(h, "block %d out of range", block);
+    const BlockInfo& bi = h->blocks[block];
+    if (C) *C = bi.C;
+    if (h_out) *h_out = H / bi.ds;
+    if (w_out) *w_out = W / bi.ds;
+    return 0;
+}
+
+int cddpm_load_weights(cddpm_handle h, const char* const* names, const float* const* host_ptrs, const int64_t* numels,
+                       int n) {
+    if (!h) return -1;
+    if (h->weights_loaded) return fail(h, "weights already loaded for this handle (create a new handle)");
+    HIPCHECK(h, hipSetDevice(h->device));
+    HostWeights hw;
+    for (int i = 0; i < n; ++i) hw.m[names[i]] = {host_ptrs[i], numels[i]};
+    for (const WeightSpec& w : h->wspecs) {
+        auto it = hw.m.find(w.name);
+        if (it == hw.m.end()) return fail(h, "missing weight '%s'", w.name.c_str());
+        if (it->second.second != w.numel)
+            return fail(h, "weight '%s' has %lld elements, expected %lld", w.name.c_str(), (long long)it->second.second,
+                        (long long)w.numel);
+        if (!it->second.first) return fail(h, "weight '%s' has a NULL pointer", w.name.c_str());
+    }
+    const int C = h->d.model_channels;
+    // embedding MLPs
+    if (h->d.cond_dim > 0) {
+        if (upload(h, &h->le0_w, hw.get("label_emb.0.weight"), (size_t)h->half * h->d.cond_dim)) return -1;
+        if (upload(h, &h->le0_b, hw.get("label_emb.0.bias"), h->half)) return -1;
+        if (upload(h, &h->le2_w, hw.get("label_emb.2.weight"), (size_t)h->half * h->half)) return -1;
+        if (upload(h, &h->le2_b, hw.get("label_emb.2.bias"), h->half)) return -1;
+    }
+    if (upload(h, &h->te0_w, hw.get("time_embed.0.weight"), (size_t)h->half * C)) return -1;
+    if (upload(h, &h->te0_b, hw.get("time_embed.0.bias"), h->half)) return -1;
+    if (upload(h, &h->te2_w, hw.get("time_embed.2.weight"), (size_t)h->half * h->half)) return -1;
+    if (upload(h, &h->te2_b, hw.get("time_embed.2.bias"), h->half)) return -1;
+    // input conv [C][1][3][3] is already [C][9]
+    if (upload(h, &h->in_w, hw.get("input_blocks.0.0.weight"), (size_t)C * 9)) return -1;
+    if (upload(h, &h->in_b, hw.get("input_blocks.0.0.bias"), C)) return -1;
+    // ResBlocks
+    std::vector<float> embw((size_t)h->sumE * h->E), embb(h->sumE);
+    for (ResW& r : h->res) {
+        if (upload_norm(h, hw, r.prefix + ".in_layers.0", r.Cin, &r.gn1)) return -1;
+        if (upload_conv(h, hw, r.prefix + ".in_layers.2", r.Cin, r.Cout, 9, &r.conv1)) return -1;
+        if (upload_norm(h, hw, r.prefix + ".out_layers.0", r.Cout, &r.gn2)) return -1;
+        if (upload_conv(h, hw, r.prefix + ".out_layers.3", r.Cout, r.Cout, 9, &r.conv2, false)) return -1;
+        std::vector<float> b2(hw.get(r.prefix + ".out_layers.3.bias"), hw.get(r.prefix + ".out_layers.3.bias") + r.Cout);
+        if (r.has_skip) {
+            if (upload_conv(h, hw, r.prefix + ".skip_connection", r.Cin, r.Cout, 1, &r.skip, false)) return -1;
+            const float* bs = hw.get(r.prefix + ".skip_connection.bias");
+            for (int i = 0; i < r.Cout; ++i) b2[i] += bs[i];
+        }
+        if (upload(h, &r.bias2, b2.data(), r.Cout)) return -1;
+        memcpy(&embw[(size_t)r.eoff * h->E], hw.get(r.prefix + ".emb_layers.1.weight"), (size_t)2 * r.Cout * h->E * sizeof(float));
+        memcpy(&embb[r.eoff], hw.get(r.prefix + ".emb_layers.1.bias"), (size_t)2 * r.Cout * sizeof(float));
+    }
+    if (upload(h, &h->emb_w, embw.data(), embw.size())) return -1;
+    if (upload(h, &h->emb_b, embb.data(), embb.size())) return -1;
+    for (AttnW& a : h->attn) {
+        if (upload_norm(h, hw, a.prefix + ".norm", a.C, &a.norm)) return -1;
+        if (upload_conv(h, hw, a.prefix + ".qkv", a.C, 3 * a.C, 1, &a.qkv)) return -1;
+        if (upload_conv(h, hw, a.prefix + ".proj_out", a.C, a.C, 1, &a.proj)) return -1;
+    }
+    // head: out.2.weight [1][C][3][3] -> [9][C]
+    {
+        const int Ch = h->blocks[h->prog[h->prog.size() - 2].block].C;
+        if (upload_norm(h, hw, "out.0", Ch, &h->out_norm)) return -1;
+        const float* w = hw.get("out.2.weight");
+        std::vector<float> w9((size_t)9 * Ch);
+        for (int c = 0; c < Ch; ++c)
+            for (int t = 0; t < 9; ++t) w9[(size_t)t * Ch + c] = w[(size_t)c * 9 + t];
+        if (upload(h, &h->head_w9, w9.data(), w9.size())) return -1;
+        h->head_bias = hw.get("out.2.bias")[0];
+    }
+    h->weights_loaded = true;
+    return 0;
+}
+
+int cddpm_set_schedule(cddpm_handle h, const float* coef1, const float* coef2, const float* logvar,
+                       const float* sqrt_recip, const float* sqrt_recipm1, int T, int objective) {
+    if (!h) return -1;
+    if (!h->weights_loaded) return fail(h, "load weights before cddpm_set_schedule (it builds the embedding tables)");
+    if (T != h->d.timesteps) return fail(h, "T=%d does not match the handle's timesteps=%d", T, h->d.timesteps);
+    if (objective != CDDPM_PRED_X0 && objective != CDDPM_PRED_NOISE) return fail(h, "unknown objective %d", objective);
+    if (!coef1 || !coef2 || !logvar) return fail(h, "coef1/coef2/logvar must not be NULL");
+    if (objective == CDDPM_PRED_NOISE && (!sqrt_recip || !sqrt_recipm1))
+        return fail(h, "pred_noise needs sqrt_recip_alphas_cumprod and sqrt_recipm1_alphas_cumprod");
+    HIPCHECK(h, hipSetDevice(h->device));
+    const float* src[5] = {coef1, coef2, logvar, sqrt_recip, sqrt_recipm1};
+    for (int i = 0; i < 5; ++i)
+        if (src[i]) HIPCHECK(h, hipMemcpy(h->sched[i], src[i], (size_t)T * sizeof(float), hipMemcpyHostToDevice));
+    h->objective = objective;
+    // time-embedding table: timestep_embedding (util.py:151-171) -> time_embed MLP (OpenAI_Unet.py:598-602)
+    // -> time half of every ResBlock's emb_layers (OpenAI_Unet.py:201-207, :300)
+    const int C = h->d.model_channels, halfdim = C / 2;
+    std::vector<float> temb((size_t)T * C, 0.f);
+    for (int t = 0; t < T; ++t)
+        for (int i = 0; i < halfdim; ++i) {
+            float a = (float)(-std::log(10000.0)) * (float)i;   // float32 arithmetic as torch does
+            a = a / (float)halfdim;
+            const float f = (float)std::exp((double)a);
+            const float arg = (float)t * f;
+            temb[(size_t)t * C + i] = (float)std::cos((double)arg);
+            temb[(size_t)t * C + halfdim + i] = (float)std::sin((double)arg);
+        }
+    hipStream_t s = nullptr;
+    HIPCHECK(h, hipMemcpy(h->scratch0, temb.data(), temb.size() * sizeof(float), hipMemcpyHostToDevice));
+    launch_linear(h->scratch0, C, h->te0_w, C, 0, h->te0_b, h->scratch1, h->half, T, h->half, C, 0, s);
+    launch_linear(h->scratch1, h->half, h->te2_w, h->half, 0, h->te2_b, h->scratch0, h->half, T, h->half, h->half, 1, s);
+    launch_linear(h->scratch0, h->half, h->emb_w, h->E, 0, nullptr, h->tab, h->sumE, T, h->sumE, h->half, 1, s);
+    HIPCHECK(h, hipGetLastError());
+    HIPCHECK(h, hipDeviceSynchronize());
+    h->schedule_set = true;
+    return 0;
+}
+
+int cddpm_prepare_cond(cddpm_handle h, const float* cond_dev, int B, void* stream) {
+    if (!h) return -1;
+    if (!h->weights_loaded) return fail(h, "weights not loaded");
+    if (B < 1 || B > h->d.max_batch) return fail(h, "B=%d outside [1, %d]", B, h->d.max_batch);
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHECK(h, hipSetDevice(h->device));
+    if (h->d.cond_dim > 0) {
+        if (!cond_dev) return fail(h, "cond_dev is NULL but the model is conditional (cond_dim=%d)", h->d.cond_dim);
+        launch_linear(cond_dev, h->d.cond_dim, h->le0_w, h->d.cond_dim, 0, h->le0_b, h->scratch1, h->half, B, h->half,
+                      h->d.cond_dim, 0, s);
+        launch_linear(h->scratch1, h->half, h->le2_w, h->half, 0, h->le2_b, h->scratch0, h->half, B, h->half, h->half, 1, s);
+        launch_linear(h->scratch0, h->half, h->emb_w, h->E, h->half, h->emb_b, h->cpart, h->sumE, B, h->sumE, h->half, 1, s);
+    } else {
+        launch_linear(h->scratch0, h->half, h->emb_w, h->E, 0, h->emb_b, h->cpart, h->sumE, B, h->sumE, 0, 0, s);
+    }
+    HIPCHECK(h, hipGetLastError());
+    h->cond_B = B;
+    return 0;
+}
+
+int cddpm_unet_forward(cddpm_handle h, const float* x_dev, const int32_t* t_dev, int t_uniform, float* out_dev, int B,
+                       int H, int W, void* stream) {
+    if (check_call(h, B, H, W)) return -1;
+    if (!x_dev || !out_dev) return fail(h, "x_dev/out_dev must not be NULL");
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHECK(h, hipSetDevice(h->device));
+    if (t_dev) {
+        HIPCHECK(h, hipMemcpyAsync(h->d_t, t_dev, (size_t)B * sizeof(int), hipMemcpyDeviceToDevice, s));
+    } else {
+        if (t_uniform < 0 || t_uniform >= h->d.timesteps) return fail(h, "t=%d outside [0, %d)", t_uniform, h->d.timesteps);
+        launch_fill_int(h->d_t, B, t_uniform, s);
+    }
+    return forward_impl(h, x_dev, out_dev, B, H, W, s);
+}
+
+int cddpm_reverse(cddpm_handle h, float* img, const float* noise_dev, uint64_t seed, uint64_t slice0, int t_start, int B,
+                  int H, int W, void* stream) {
+    if (check_call(h, B, H, W)) return -1;
+    if (!img) return fail(h, "img_inout_dev is NULL");
+    if (t_start < 1 || t_start > h->d.timesteps) return fail(h, "t_start=%d outside [1, %d]", t_start, h->d.timesteps);
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHECK(h, hipSetDevice(h->device));
+    const int HW = H * W;
+    for (int t = t_start - 1; t >= 0; --t) {
+        launch_fill_int(h->d_t, B, t, s);
+        if (forward_impl(h, img, h->model_out, B, H, W, s)) return -1;
+        StepArgs a;
+        a.x = img; a.model_out = h->model_out; a.t_dev = h->d_t;
+        a.coef1 = h->sched[0]; a.coef2 = h->sched[1]; a.logvar = h->sched[2];
+        a.sqrt_recip = h->sched[3]; a.sqrt_recipm1 = h->sched[4];
+        a.objective = h->objective;
+        a.noise = noise_dev ? noise_dev + (size_t)t * B * HW : nullptr;
+        a.seed = seed; a.slice0 = slice0; a.t_for_rng = t;
+        a.B = B; a.HW = HW; a.finalize = (t == 0);
+        launch_step(a, s);
+    }
+    HIPCHECK(h, hipGetLastError());
+    return 0;
+}
+
+int cddpm_noise_fill(cddpm_handle h, float* out_dev, uint64_t seed, uint32_t stream_id, int t, uint64_t slice0, int B,
+                     int H, int W, void* stream) {
+    if (!h) return -1;
+    if (!out_dev || B < 1 || H < 1 || W < 1 || (H * W) % 4) return fail(h, "bad arguments to cddpm_noise_fill");
+    HIPCHECK(h, hipSetDevice(h->device));
+    launch_noise_fill(out_dev, seed, stream_id, t, slice0, B, H * W, (hipStream_t)stream);
+    HIPCHECK(h, hipGetLastError());
+    return 0;
+}
+
+int cddpm_q_sample(cddpm_handle h, const float* x01_dev, const float* noise_dev, const int32_t* t_dev, int t_uniform,
+                   const float* sqrt_ac_host, const float* sqrt_1mac_host, int T, float* out_dev, int B, int H, int W,
+                   void* stream) {
+    if (!h) return -1;
+    if (T != h->d.timesteps) return fail(h, "T mismatch");
+    if (B < 1 || B > h->d.max_batch || (H * W) % 4) return fail(h, "bad B/H/W");
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHECK(h, hipSetDevice(h->device));
+    HIPCHECK(h, hipMemcpyAsync(h->qs_sa, sqrt_ac_host, (size_t)T * sizeof(float), hipMemcpyHostToDevice, s));
+    HIPCHECK(h, hipMemcpyAsync(h->qs_s1, sqrt_1mac_host, (size_t)T * sizeof(float), hipMemcpyHostToDevice, s));
+    if (t_dev) HIPCHECK(h, hipMemcpyAsync(h->d_t, t_dev, (size_t)B * sizeof(int), hipMemcpyDeviceToDevice, s));
+    else launch_fill_int(h->d_t, B, t_uniform, s);
+    launch_q_sample(x01_dev, noise_dev, h->d_t, h->qs_sa, h->qs_s1, out_dev, B, H * W, s);
+    HIPCHECK(h, hipGetLastError());
+    return 0;
+}
+
+// ---- standalone ops for kernel tests ---------------------------------------------------------------
+int cddpm_op_conv(cddpm_handle h, const float* src0, int C0, const float* src1, int C1, const float* coef_dev, int silu,
+                  int upsample, const float* w_host, const float* bias_host, int Cout, int ksize, const float* res_dev,
+                  int res_upsample, float* out_dev, int B, int H, int W, void* stream) {
+    if (!h) return -1;
+    const int Cin = C0 + C1, taps = ksize * ksize;
+    if ((ksize != 1 && ksize != 3) || C0 % 32 || C1 % 32 || Cin <= 0 || Cout % 128 || Cout <= 0)
+        return fail(h, "cddpm_op_conv: unsupported shape (ksize %d, C0 %d, C1 %d, Cout %d)", ksize, C0, C1, Cout);
+    if (upsample && (H % 2 || W % 2)) return fail(h, "upsample needs even H, W");
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHECK(h, hipSetDevice(h->device));
+    std::vector<float> pk(packed_conv_floats(Cout, Cin, taps));
+    pack_conv_weights(w_host, Cout, Cin, taps, pk.data());
+    float *dw = nullptr, *db = nullptr;
+    HIPCHECK(h, hipMalloc((void**)&dw, pk.size() * sizeof(float)));
+    HIPCHECK(h, hipMalloc((void**)&db, (size_t)Cout * sizeof(float)));
+    HIPCHECK(h, hipMemcpy(dw, pk.data(), pk.size() * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHECK(h, hipMemcpy(db, bias_host, (size_t)Cout * sizeof(float), hipMemcpyHostToDevice));
+    ConvArgs a;
+    zero_conv_args(a);
+    a.src0 = src0; a.C0 = C0; a.src1 = src1; a.C1 = C1;
+    a.srcH = upsample ? H / 2 : H; a.srcW = upsample ? W / 2 : W; a.upsample = upsample;
+    a.coef = coef_dev; a.silu = silu; a.wpk = dw; a.bias = db; a.res = res_dev; a.res_up = res_upsample;
+    a.out = out_dev; a.B = B; a.H = H; a.W = W; a.Cout = Cout; a.taps = taps;
+    launch_conv(a, s);
+    HIPCHECK(h, hipGetLastError());
+    HIPCHECK(h, hipStreamSynchronize(s));
+    (void)hipFree(dw);
+    (void)hipFree(db);
+    return 0;
+}
+
+int cddpm_op_gn_coef(cddpm_handle h, const float* src0, int C0, const float* src1, int C1, const float* gamma_host,
+                     const float* beta_host, const float* film_dev, float* coef_dev, int B, int HW, void* stream) {
+    if (!h) return -1;
+    const int C = C0 + C1;
+    if (C0 % 4 || C1 % 4 || C % 32 || C > 1024 || C0 > 1024) return fail(h, "cddpm_op_gn_coef: unsupported channels");
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHECK(h, hipSetDevice(h->device));
+    const int ns = gn_nsplit(B, HW);
+    double* part = nullptr;
+    float *g = nullptr, *bt = nullptr;
+    HIPCHECK(h, hipMalloc((void**)&part, (size_t)B * ns * C * 2 * sizeof(double)));
+    HIPCHECK(h, hipMalloc((void**)&g, (size_t)C * sizeof(float)));
+    HIPCHECK(h, hipMalloc((void**)&bt, (size_t)C * sizeof(float)));
+    HIPCHECK(h, hipMemcpy(g, gamma_host, (size_t)C * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHECK(h, hipMemcpy(bt, beta_host, (size_t)C * sizeof(float), hipMemcpyHostToDevice));
+    launch_gn_partial(src0, C0, C, 0, B, HW, ns, part, s);
+    if (src1) launch_gn_partial(src1, C1, C, C0, B, HW, ns, part, s);
+    launch_gn_finalize(part, ns, C, B, HW, g, bt, nullptr, nullptr, 0, 0, nullptr, film_dev, coef_dev, s);
+    HIPCHECK(h, hipGetLastError());
+    HIPCHECK(h, hipStreamSynchronize(s));
+    (void)hipFree(part);
+    (void)hipFree(g);
+    (void)hipFree(bt);
+    return 0;
+}
+
+int cddpm_op_attention(cddpm_handle h, const float* qkv_dev, float* out_dev, int B, int N, int C, void* stream) {
+    if (!h) return -1;
+    if (C % 64 || N < 1) return fail(h, "cddpm_op_attention: C must be a multiple of 64");
+    HIPCHECK(h, hipSetDevice(h->device));
+    launch_attention(qkv_dev, out_dev, B, N, C, (hipStream_t)stream);
+    HIPCHECK(h, hipGetLastError());
+    return 0;
+}
+
+}  // extern "C"

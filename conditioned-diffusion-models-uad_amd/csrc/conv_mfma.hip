@@ -1,0 +1,287 @@
+// Fused implicit-GEMM convolution for gfx950 (MI355X), exact fp32 on v_mfma_f32_32x32x2_f32.
+//
+// Replaces, inside every ResBlock / AttentionBlock of the reference UNet
+// (src/models/modules/OpenAI_Unet.py:284-338, :386-394), the chain
+//     GroupNorm32 -> [FiLM] -> SiLU -> [nearest x2] -> [torch.cat] -> Conv2d(3x3 | 1x1) -> [+ skip]
+// with ONE kernel: normalisation/FiLM arrive as per-(sample, channel) coefficients (mean, a, d) computed by
+// norm_kernels.hip and are applied while the input patch is staged into LDS; the channel concat of the
+// up path (OpenAI_Unet.py:948) is two source pointers; the nearest-neighbour upsample (:118-128) is an
+// index shift; the residual add / 1x1 skip_connection (:261-268, :336) is the epilogue / a second K segment.
+//
+// GEMM view:  D[pixel][cout] = sum_{tap, ci} act(X)[pixel + tap][ci] * Wt[tap][ci][cout]
+//   M = 128 pixels  (4 image rows x 32 columns),  N = 128 output channels,  K step = 32 input channels x 1 tap.
+//   4 waves, each owns a 64 x 64 sub-tile = 2 x 2 MFMA tiles of 32 x 32 (64 accumulator VGPRs).
+// LDS (58.9 KB for 3x3 -> 2 workgroups per CU):
+//   act patch   : (4+2) x (32+2) pixels x 32 channels, one 128-B row per pixel, 16-B slot s stored at
+//                 s ^ ((pixel>>1)&7)  -> ds_read_b128 of 16 consecutive pixels is bank-conflict free
+//   weight slab : 2 buffers x [128 cout][32 ci], same swizzle; the packed global image IS the LDS image, so
+//                 staging is a linear 16-B copy.
+// Each lane fetches 4 consecutive channels per ds_read_b128 and feeds them to 4 successive MFMAs; the K order
+// inside a 8-channel group is therefore {c, c+4} pairs -- identical for A and B, so the sum is unchanged.
+#include "kernels.h"
+
+namespace cddpm {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float v4f __attribute__((ext_vector_type(4)));   // native vector: stays in registers (HIP's float4 struct arrays may not)
+
+__device__ __forceinline__ float silu_f(float v) {
+    // v * sigmoid(v); v_exp_f32 + v_rcp_f32 (<= 2 ulp), no overflow issue: exp(+large) = inf -> rcp = 0
+    return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));
+}
+
+template <int TAPS>
+__global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
+    constexpr int PAD = (TAPS == 9) ? 1 : 0;
+    constexpr int PW = 32 + 2 * PAD;            // patch width  (pixels)
+    constexpr int PH = 4 + 2 * PAD;             // patch height (pixels)
+    constexpr int NPIX = PW * PH;               // 204 | 128
+    constexpr int NK = (NPIX * 8 + 255) / 256;  // v4f patch entries per thread: 7 | 4
+
+    extern __shared__ v4f lds[];
+    v4f* ldsA = lds;                // NPIX * 8 v4f
+    v4f* ldsW = lds + NPIX * 8;     // 2 * 1024 v4f
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int li = lane & 31;
+    const int lh = lane >> 5;
+    const int wm = wave & 1;    // pixel rows {0,1} | {2,3}
+    const int wn = wave >> 1;   // cout 0..63 | 64..127
+
+    const int ncb = a.Cout >> 7;
+    const int tilesX = (a.W + 31) >> 5;
+    const int tilesY = (a.H + 3) >> 2;
+    int bid = blockIdx.x;
+    const int cb = bid % ncb;
+    bid /= ncb;
+    const int tx = bid % tilesX;
+    bid /= tilesX;
+    const int ty = bid % tilesY;
+    const int b = bid / tilesY;
+    const int y0 = ty * 4, x0 = tx * 32;
+
+    const int Cin = a.C0 + a.C1;
+    const int nch_main = Cin >> 5;
+    const int nch_skip = (a.S0 + a.S1) >> 5;
+    const int nch = nch_main + nch_skip;
+
+    // ---- per-thread patch entries: slot s is fixed per thread, pixel q = (tid>>3) + 32k
+    const int s = tid & 7;
+    int psrc[NK];    // source pixel index (main segment), -1 = zero padding / outside
+    int pskip[NK];   // source pixel index (skip segment, output resolution, centre pixels only)
+    int ldsoff[NK];
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+        const int q = (tid >> 3) + 32 * k;
+        const int pr = q / PW, pc = q - pr * PW;
+        const int y = y0 + pr - PAD, x = x0 + pc - PAD;
+        const bool valid = (q < NPIX) && (y >= 0) && (y < a.H) && (x >= 0) && (x < a.W);
+        const int sy = a.upsample ? (y >> 1) : y, sx = a.upsample ? (x >> 1) : x;
+        psrc[k] = valid ? ((b * a.srcH + sy) * a.srcW + sx) : -1;
+        const bool centre = valid && (pr >= PAD) && (pr < PH - PAD) && (pc >= PAD) && (pc < PW - PAD);
+        pskip[k] = centre ? ((b * a.H + y) * a.W + x) : -1;
+        ldsoff[k] = (q < NPIX) ? (q * 8 + (s ^ ((q >> 1) & 7))) : -1;
+    }
+
+    const v4f* wmain = reinterpret_cast<const v4f*>(a.wpk) + (size_t)cb * nch_main * TAPS * 1024;
+    const v4f* wskip = reinterpret_cast<const v4f*>(a.skip_wpk) + (size_t)cb * nch_skip * 1024;
+
+    v4f wreg[4];
+    v4f areg[NK];
+    v4f cm, ca, cd;   // coefficients of this thread's 4 channels for the chunk held in areg
+    bool have_coef = false;
+
+    // stage pointer: slab of (chunk, tap); past the end it wraps to stage 0 so the prefetch stays unconditional
+    auto wslab = [&](int chunk, int tap) -> const v4f* {
+        if (chunk >= nch) { chunk = 0; tap = 0; }
+        return (chunk < nch_main) ? (wmain + ((size_t)chunk * TAPS + tap) * 1024)
+                                  : (wskip + (size_t)(chunk - nch_main) * 1024);
+    };
+    auto load_act = [&](int chunk) {
+        const float* base;
+        int Cs, c0;
+        const bool main_seg = chunk < nch_main;
+        if (main_seg) {
+            const int ch = chunk << 5;
+            if (ch < a.C0) { base = a.src0; Cs = a.C0; c0 = ch; }
+            else           { base = a.src1; Cs = a.C1; c0 = ch - a.C0; }
+            have_coef = (a.coef != nullptr);
+            if (have_coef) {
+                const size_t ci = (size_t)b * Cin + ch + 4 * s;
+                const size_t plane = (size_t)a.B * Cin;
+                cm = *reinterpret_cast<const v4f*>(a.coef + ci);
+                ca = *reinterpret_cast<const v4f*>(a.coef + plane + ci);
+                cd = *reinterpret_cast<const v4f*>(a.coef + 2 * plane + ci);
+            }
+        } else {
+            const int ch = (chunk - nch_main) << 5;
+            if (ch < a.S0) { base = a.skip0; Cs = a.S0; c0 = ch; }
+            else           { base = a.skip1; Cs = a.S1; c0 = ch - a.S0; }
+            have_coef = false;
+        }
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+            const int p = main_seg ? psrc[k] : pskip[k];
+            v4f v = v4f{0.f, 0.f, 0.f, 0.f};
+            if (p >= 0) v = *reinterpret_cast<const v4f*>(base + (size_t)p * Cs + c0 + 4 * s);
+            areg[k] = v;
+        }
+    };
+    auto store_act = [&](int chunk) {
+        const bool main_seg = chunk < nch_main;
+        const bool do_silu = main_seg && a.silu;
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+            v4f v = areg[k];
+            const int p = main_seg ? psrc[k] : pskip[k];
+            if (p >= 0) {   // zero padding stays exactly zero: the conv pads AFTER the activation
+                if (have_coef) {
+                    v.x = (v.x - cm.x) * ca.x + cd.x;
+                    v.y = (v.y - cm.y) * ca.y + cd.y;
+                    v.z = (v.z - cm.z) * ca.z + cd.z;
+                    v.w = (v.w - cm.w) * ca.w + cd.w;
+                }
+                if (do_silu) { v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w); }
+            }
+            if (ldsoff[k] >= 0) ldsA[ldsoff[k]] = v;
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // B operand (weights) LDS offsets: row j = cout within the 128 block
+    int boff[2], bsw[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int j = 64 * wn + 32 * nt + li;
+        boff[nt] = j * 8;
+        bsw[nt] = (j >> 1) & 7;
+    }
+
+    auto compute = [&](int tap, int buf) {
+        const int ky = (TAPS == 9) ? (tap / 3) : 0;
+        const int kx = (TAPS == 9) ? (tap - 3 * ky) : 0;
+        int aoff[2], asw[2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const int q = (2 * wm + mt + ky) * PW + li + kx;
+            aoff[mt] = q * 8;
+            asw[mt] = (q >> 1) & 7;
+        }
+        const v4f* wb = ldsW + buf * 1024;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int sl = 2 * g + lh;
+            const v4f a0 = ldsA[aoff[0] + (sl ^ asw[0])];
+            const v4f a1 = ldsA[aoff[1] + (sl ^ asw[1])];
+            const v4f b0 = wb[boff[0] + (sl ^ bsw[0])];
+            const v4f b1 = wb[boff[1] + (sl ^ bsw[1])];
+            const float av0[4] = {a0.x, a0.y, a0.z, a0.w};
+            const float av1[4] = {a1.x, a1.y, a1.z, a1.w};
+            const float bv0[4] = {b0.x, b0.y, b0.z, b0.w};
+            const float bv1[4] = {b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[m], bv0[m], acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[m], bv1[m], acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[m], bv0[m], acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[m], bv1[m], acc[1][1], 0, 0, 0);
+            }
+        }
+    };
+
+    // ---- main loop: weights double-buffered in LDS and prefetched through registers one stage ahead;
+    //      the next chunk's patch is fetched into registers behind the last tap's MFMAs.
+    {
+        const v4f* p0 = wslab(0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wreg[i] = p0[tid + 256 * i];
+    }
+    load_act(0);
+    int buf = 0;
+    for (int chunk = 0; chunk < nch; ++chunk) {
+        const bool main_seg = chunk < nch_main;
+        const int ntap = main_seg ? TAPS : 1;
+        __syncthreads();   // every wave is done reading the previous patch
+        store_act(chunk);
+        for (int t = 0; t < ntap; ++t) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ldsW[buf * 1024 + tid + 256 * i] = wreg[i];
+            const bool last_tap = (t == ntap - 1);
+            const v4f* pn = last_tap ? wslab(chunk + 1, 0) : wslab(chunk, t + 1);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) wreg[i] = pn[tid + 256 * i];
+            if (last_tap && chunk + 1 < nch) load_act(chunk + 1);
+            __syncthreads();
+            compute(main_seg ? t : (TAPS / 2), buf);   // skip segment: centre tap
+            buf ^= 1;
+        }
+    }
+
+    // ---- epilogue: D row = pixel (r&3) + 8 (r>>2) + 4 lh, D col = cout li
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const int y = y0 + 2 * wm + mt;
+        if (y >= a.H) continue;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int co = cb * 128 + 64 * wn + 32 * nt + li;
+            const float bias = a.bias ? a.bias[co] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int x = x0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (x < a.W) {
+                    float v = acc[mt][nt][r] + bias;
+                    if (a.res) {
+                        const size_t rp = a.res_up ? ((size_t)(b * (a.H >> 1) + (y >> 1)) * (a.W >> 1) + (x >> 1))
+                                                   : ((size_t)(b * a.H + y) * a.W + x);
+                        v += a.res[rp * a.Cout + co];
+                    }
+                    a.out[((size_t)(b * a.H + y) * a.W + x) * a.Cout + co] = v;
+                }
+            }
+        }
+    }
+}
+
+void launch_conv(const ConvArgs& a, hipStream_t stream) {
+    const int tilesX = (a.W + 31) / 32, tilesY = (a.H + 3) / 4;
+    const unsigned grid = (unsigned)(a.B * tilesX * tilesY * (a.Cout / 128));
+    if (a.taps == 9) {
+        const size_t lds = (size_t)(6 * 34 * 8 + 2048) * 16;
+        hipLaunchKernelGGL(conv_mfma_kernel<9>, dim3(grid), dim3(256), lds, stream, a);
+    } else {
+        const size_t lds = (size_t)(4 * 32 * 8 + 2048) * 16;
+        hipLaunchKernelGGL(conv_mfma_kernel<1>, dim3(grid), dim3(256), lds, stream, a);
+    }
+}
+
+size_t packed_conv_floats(int Cout, int Cin, int taps) { return (size_t)Cout * Cin * taps; }
+
+// w: PyTorch [Cout][Cin][k][k] (taps = k*k, tap = ky*3+kx) -> [Cout/128][Cin/32][taps][128][8 slots][4]
+void pack_conv_weights(const float* w, int Cout, int Cin, int taps, float* dst) {
+    const int ncb = Cout / 128, nch = Cin / 32;
+    for (int cb = 0; cb < ncb; ++cb)
+        for (int ch = 0; ch < nch; ++ch)
+            for (int t = 0; t < taps; ++t) {
+                float* img = dst + (((size_t)cb * nch + ch) * taps + t) * 4096;
+                for (int j = 0; j < 128; ++j)
+                    for (int sl = 0; sl < 8; ++sl) {
+                        float* d4 = img + (size_t)(j * 8 + (sl ^ ((j >> 1) & 7))) * 4;
+                        for (int e = 0; e < 4; ++e) {
+                            const int co = cb * 128 + j, ci = ch * 32 + sl * 4 + e;
+                            d4[e] = w[((size_t)co * Cin + ci) * taps + t];
+                        }
+                    }
+            }
+}
+
+}  // namespace cddpm

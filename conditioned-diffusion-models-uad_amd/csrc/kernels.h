@@ -1,0 +1,92 @@
+// Internal launcher interface of libcddpm_hip.so (gfx950 only). Each launcher enqueues on `stream`
+// and returns; shape preconditions are checked by the callers in cddpm_api.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace cddpm {
+
+// ------------------------------------------------------------------------------------------------
+// Fused implicit-GEMM convolution (conv_mfma.hip). NHWC activations, M = pixels, N = output channels,
+// K = taps x input channels, v_mfma_f32_32x32x2_f32 (exact fp32).
+// ------------------------------------------------------------------------------------------------
+struct ConvArgs {
+    const float* src0;   // NHWC [B, srcH, srcW, C0]
+    const float* src1;   // NHWC [B, srcH, srcW, C1] or nullptr: channels C0.. of the concatenation
+    int C0, C1;          // Cin = C0 + C1, both multiples of 32
+    int srcH, srcW;      // source extent (H/2, W/2 when upsample)
+    int upsample;        // 1: nearest x2, source pixel (y>>1, x>>1)
+    const float* coef;   // [3][B][Cin] (mean, a, d) or nullptr: v -> (v - mean) * a + d
+    int silu;            // 1: v -> v * sigmoid(v) after the affine map
+    const float* wpk;    // packed weights, see pack_conv_weights()
+    const float* bias;   // [Cout]
+    const float* res;    // residual NHWC [B, resH, resW, Cout] or nullptr
+    int res_up;          // 1: residual lives at half resolution, read at (y>>1, x>>1)
+    float* out;          // NHWC [B, H, W, Cout]
+    int B, H, W, Cout;   // Cout multiple of 128
+    int taps;            // 9 (3x3, zero pad 1) or 1
+    // second K segment (optional): an un-normalised 1x1 convolution accumulated into the same tile,
+    // used for ResBlock skip_connection convs: out += conv1x1(skip0|skip1) (bias folded by the caller)
+    const float* skip0; const float* skip1; int S0, S1;   // NHWC at the OUTPUT resolution
+    const float* skip_wpk;
+};
+void launch_conv(const ConvArgs& a, hipStream_t stream);
+
+// packed weight image sizes / packing (host side, cddpm_api.hip)
+// layout: [Cout/128][Cin/32][taps][128 rows x 8 slots of float4], slot s of row j stored at s ^ ((j>>1)&7)
+size_t packed_conv_floats(int Cout, int Cin, int taps);
+void pack_conv_weights(const float* w /*[Cout][Cin][k][k]*/, int Cout, int Cin, int taps, float* dst);
+
+// ------------------------------------------------------------------------------------------------
+// GroupNorm(32) statistics and per-(sample, channel) coefficients (norm_kernels.hip)
+// ------------------------------------------------------------------------------------------------
+// partial per-channel sums: part[b][split][Ctot][2] (double), this launch fills channels [coff, coff+C)
+void launch_gn_partial(const float* src, int C, int Ctot, int coff, int B, int HW, int nsplit, double* part,
+                       hipStream_t stream);
+int gn_nsplit(int B, int HW);
+// coef[0][b][c] = mean_g, coef[1] = rstd*gamma*(1+scale), coef[2] = beta*(1+scale)+shift
+// scale/shift = tab[t_b][eoff + c] + cpart[b][eoff + c] (scale) and [.. + C + c] (shift) when tab != nullptr
+void launch_gn_finalize(const double* part, int nsplit, int C, int B, int HW, const float* gamma, const float* beta,
+                        const float* tab, const float* cpart, int sumE, int eoff, const int* t_dev,
+                        const float* film_direct, float* coef, hipStream_t stream);
+
+// ------------------------------------------------------------------------------------------------
+// small memory-bound kernels (small_kernels.hip)
+// ------------------------------------------------------------------------------------------------
+// 3x3 conv with one input channel: x [B,H,W] -> out NHWC [B,H,W,C]; w [C][9], bias [C]
+void launch_conv_in1(const float* x, const float* w, const float* bias, float* out, int B, int H, int W, int C,
+                     hipStream_t stream);
+// head: per pixel 9 partial dot products of act(x) with w[tap][C] -> P[B,HW,9]; then gather to out [B,H,W]
+void launch_head_dots(const float* x, const float* coef, const float* w9 /*[9][C]*/, float* P, int B, int HW, int C,
+                      hipStream_t stream);
+void launch_head_gather(const float* P, float bias, float* out, int B, int H, int W, hipStream_t stream);
+// down ResBlock front end: hp = avgpool2(silu(affine(x))), xp = avgpool2(x); NHWC
+void launch_pool_act(const float* x, const float* coef, float* hp, float* xp, int B, int H, int W, int C,
+                     hipStream_t stream);
+// y[M][N] = act(x)[M][K] . W[N][ldw (cols koff..koff+K)]^T + bias ; silu_in applies SiLU to x first
+void launch_linear(const float* x, int ldx, const float* W, int ldw, int koff, const float* bias, float* y, int ldy,
+                   int M, int N, int K, int silu_in, hipStream_t stream);
+void launch_fill_int(int* p, int n, int v, hipStream_t stream);
+
+// posterior step (cond_DDPM.py:391-444): x <- c1[t] * x0hat + c2[t] * x + exp(0.5 logvar[t]) * z (t > 0)
+struct StepArgs {
+    float* x; const float* model_out; const int* t_dev;
+    const float* coef1; const float* coef2; const float* logvar; const float* sqrt_recip; const float* sqrt_recipm1;
+    int objective;
+    const float* noise;          // explicit z for this step [B,HW] or nullptr -> Philox
+    uint64_t seed, slice0; int t_for_rng;
+    int B, HW;
+    int finalize;                // 1: also map to [0,1]: (x+1)/2 (cond_DDPM.py:463)
+};
+void launch_step(const StepArgs& a, hipStream_t stream);
+void launch_noise_fill(float* out, uint64_t seed, uint32_t stream_id, int t, uint64_t slice0, int B, int HW,
+                       hipStream_t stream);
+void launch_q_sample(const float* x01, const float* noise, const int* t_dev, const float* sa, const float* s1ma,
+                     float* out, int B, int HW, hipStream_t stream);
+
+// ------------------------------------------------------------------------------------------------
+// attention core (attention.hip): qkv NHWC [B,N,3C] -> out [B,N,C], heads of 64 channels
+// ------------------------------------------------------------------------------------------------
+void launch_attention(const float* qkv, float* out, int B, int N, int C, hipStream_t stream);
+
+}  // namespace cddpm

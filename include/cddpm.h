@@ -1,0 +1,152 @@
+/*
+ * cddpm.h -- C ABI of libcddpm_hip.so: the MI355X (gfx950) implementation of the cDDPM
+ * reverse-diffusion reconstruction path.
+ *
+ * The reference (raymondfdavey/Conditioned-Diffusion-Models-UAD) is pure Python/PyTorch and has no
+ * native interface; each entry point below names the reference Python code it replaces
+ * (paths relative to the reference root). Plain pointers and sizes only: no torch types.
+ *
+ * Conventions
+ *   - return value: 0 = ok, negative = error; text via cddpm_last_error().
+ *   - "dev" pointers are device (HIP) pointers to contiguous fp32; "host" pointers are host memory.
+ *   - images are [B,1,H,W] fp32 (single channel, so NCHW == NHWC); H and W multiples of 4.
+ *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream); all work is
+ *     enqueued on it, nothing synchronises with the host inside forward/reverse calls.
+ *   - one handle per device; a handle is not thread-safe.
+ */
+#ifndef CDDPM_H
+#define CDDPM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct cddpm_ctx* cddpm_handle;
+
+#define CDDPM_MAX_LEVELS 8
+
+/* Shape contract of the denoiser: the constructor arguments of UNetModel
+ * (src/models/modules/OpenAI_Unet.py:513-539) as DDPM_2D passes them (src/models/DDPM_2D.py:37-59):
+ * resblock_updown=True, use_scale_shift_norm=True, use_new_attention_order=True, dims=2, dropout=0. */
+typedef struct cddpm_unet_desc {
+    int32_t in_channels;                               /* 1 */
+    int32_t out_channels;                              /* 1 */
+    int32_t model_channels;                            /* cfg.unet_dim = 128 (multiple of 128) */
+    int32_t num_levels;                                /* len(channel_mult) */
+    int32_t channel_mult[CDDPM_MAX_LEVELS];            /* cfg.dim_mults = [1,2,2] */
+    int32_t num_res_blocks;                            /* 3 */
+    int32_t num_attention_resolutions;                 /* len(attention_resolutions) */
+    int32_t attention_resolutions[CDDPM_MAX_LEVELS];   /* (3,6,12): never matches ds in {1,2,4} */
+    int32_t head_channels;                             /* num_head_channels = 64 */
+    int32_t cond_dim;                                  /* num_classes slot = context width 128; 0 = unconditional */
+    int32_t timesteps;                                 /* GaussianDiffusion timesteps T */
+    int32_t max_batch;                                 /* largest B of any later call */
+    int32_t max_h, max_w;                              /* largest H, W of any later call */
+} cddpm_unet_desc;
+
+/* objective values for cddpm_set_schedule (src/models/modules/cond_DDPM.py:318) */
+#define CDDPM_PRED_X0 0
+#define CDDPM_PRED_NOISE 1
+
+/* Replaces UNetModel.__init__ + GaussianDiffusion.__init__ buffer allocation. Allocates packed-weight
+ * storage, embedding tables and the activation workspace once; no hipMalloc happens later. */
+int cddpm_create(cddpm_handle* out, const cddpm_unet_desc* desc, int device);
+void cddpm_destroy(cddpm_handle h);
+/* message of the last failing call on h (h == NULL: last failing cddpm_create) */
+const char* cddpm_last_error(cddpm_handle h);
+/* device bytes cddpm_create will allocate for this descriptor */
+size_t cddpm_workspace_bytes(const cddpm_unet_desc* desc);
+
+/* The state_dict entries the library consumes, in the reference's naming
+ * (`diffusion.model.` prefix stripped): time_embed.0.weight, input_blocks.1.0.in_layers.2.weight, ...
+ * (SURVEY.md 8a 'State-dict naming'; src/models/modules/OpenAI_Unet.py:583-797). */
+int cddpm_num_weights(cddpm_handle h);
+const char* cddpm_weight_name(cddpm_handle h, int i);
+int64_t cddpm_weight_numel(cddpm_handle h, int i);
+
+/* Replaces model.load_state_dict (src/train.py:161). `host_ptrs[i]` is the fp32 tensor `names[i]` in
+ * PyTorch layout (Conv2d [Cout,Cin,kh,kw], Linear [out,in], Conv1d [Cout,Cin,1]); the library re-packs
+ * into its own MFMA tile images and uploads. The caller keeps ownership. Every name reported by
+ * cddpm_weight_name must be present; extra names are ignored. */
+int cddpm_load_weights(cddpm_handle h, const char* const* names, const float* const* host_ptrs,
+                       const int64_t* numels, int n);
+
+/* Replaces the registered schedule buffers GaussianDiffusion reads in q_posterior / p_sample
+ * (src/models/modules/cond_DDPM.py:366-371, :391-398, :444). Host arrays of length T:
+ * posterior_mean_coef1, posterior_mean_coef2, posterior_log_variance_clipped,
+ * sqrt_recip_alphas_cumprod, sqrt_recipm1_alphas_cumprod (last two only read for CDDPM_PRED_NOISE).
+ * Also (re)builds the per-ResBlock time-embedding tables, so weights must be loaded first. */
+int cddpm_set_schedule(cddpm_handle h, const float* coef1, const float* coef2, const float* logvar,
+                       const float* sqrt_recip, const float* sqrt_recipm1, int T, int objective);
+
+/* Replaces label_emb(cond) and the cond half of every ResBlock's emb_layers
+ * (src/models/modules/OpenAI_Unet.py:583-590, :849-852, :300): computed once per batch, not per step.
+ * cond_dev: [B, cond_dim]. */
+int cddpm_prepare_cond(cddpm_handle h, const float* cond_dev, int B, void* stream);
+
+/* Replaces UNetModel.forward / forward_with_cond_scale (src/models/modules/OpenAI_Unet.py:814-1006).
+ * x_dev [B,1,H,W] -> out_dev [B,1,H,W]. t_dev: int32 [B] per-sample timesteps on the device, or NULL to
+ * use t_uniform for every sample. Uses the context prepared by cddpm_prepare_cond for the same B. */
+int cddpm_unet_forward(cddpm_handle h, const float* x_dev, const int32_t* t_dev, int t_uniform,
+                       float* out_dev, int B, int H, int W, void* stream);
+
+/* Replaces GaussianDiffusion.p_sample_loop, Gaussian branch (src/models/modules/cond_DDPM.py:446-464)
+ * including p_sample / p_mean_variance / model_predictions / q_posterior (:391-444):
+ * img_inout_dev holds x_T on entry ([B,1,H,W], N(0,1)) and the reconstruction in [0,1] on return.
+ * Runs steps t = t_start-1 .. 0 (the reference's T = num_timesteps if start_t == 0 else start_t, :449,
+ * is resolved by the caller). noise_dev: z_t at noise_dev + t*B*H*W for t in [1, t_start) (slot 0 unused),
+ * or NULL to draw z_t on the device with Philox4x32-10 keyed (seed; quad, t, slice0 + b, stream)
+ * -- see conditioned-diffusion-models-uad_amd/synth.py. */
+int cddpm_reverse(cddpm_handle h, float* img_inout_dev, const float* noise_dev, uint64_t seed,
+                  uint64_t slice0, int t_start, int B, int H, int W, void* stream);
+
+/* Replaces torch.randn(shape) / torch.randn_like (src/models/modules/cond_DDPM.py:454, :440) with the
+ * counter RNG: out_dev [B,1,H,W] ~ N(0,1); stream_id 0x1001 = x_T, 0x1002 = z_t. */
+int cddpm_noise_fill(cddpm_handle h, float* out_dev, uint64_t seed, uint32_t stream_id, int t,
+                     uint64_t slice0, int B, int H, int W, void* stream);
+
+/* Replaces q_sample (src/models/modules/cond_DDPM.py:548-554) fused with normalize_to_neg_one_to_one (:75):
+ * out = sqrt_ac[t_b] * (2 x01 - 1) + sqrt_1mac[t_b] * noise; coefficient tables are host arrays [T]
+ * uploaded on first use. Used by the single-step reconstruction (GaussianDiffusion.forward, :647-655). */
+int cddpm_q_sample(cddpm_handle h, const float* x01_dev, const float* noise_dev, const int32_t* t_dev, int t_uniform,
+                   const float* sqrt_ac_host, const float* sqrt_1mac_host, int T,
+                   float* out_dev, int B, int H, int W, void* stream);
+
+/* ---- test / debug surface (used by tests/ only) ------------------------------------------------- */
+
+/* number of blocks in the forward program and their names ("input_blocks.3", "middle_block.1", ...) */
+int cddpm_num_blocks(cddpm_handle h);
+const char* cddpm_block_name(cddpm_handle h, int i);
+/* ask the next cddpm_unet_forward calls to copy block i's output (NHWC [B,h,w,C] fp32) to dst_dev
+ * (NULL clears); channels/height/width of that output for the given input size via cddpm_block_shape */
+int cddpm_set_tap(cddpm_handle h, int block, float* dst_dev);
+int cddpm_block_shape(cddpm_handle h, int block, int H, int W, int* C, int* h_out, int* w_out);
+
+/* standalone fused convolution on NHWC tensors (the kernel behind every ResBlock conv), for kernel tests:
+ * out[B,H,W,Cout] = conv_k(act(cat[src0,src1])) + bias (+ res), k in {1,3}, zero padding k/2, optional
+ * nearest x2 upsampling of the sources (srcs are then [B,H/2,W/2,*]) and of the residual.
+ * act(v) = silu?( (v - mean[b,c]) * a[b,c] + d[b,c] ) when coef_dev != NULL (coef_dev = [3][B][Cin]: mean, a, d).
+ * w_host is PyTorch layout [Cout,Cin,k,k]. */
+int cddpm_op_conv(cddpm_handle h, const float* src0_dev, int C0, const float* src1_dev, int C1,
+                  const float* coef_dev, int silu, int upsample,
+                  const float* w_host, const float* bias_host, int Cout, int ksize,
+                  const float* res_dev, int res_upsample,
+                  float* out_dev, int B, int H, int W, void* stream);
+
+/* standalone GroupNorm(32) statistics + coefficient kernel pair: coef_dev [3][B][C] (mean, a, d) with
+ * a = rstd*gamma*(1+scale), d = beta*(1+scale)+shift; film_dev = [B][2C] (scale | shift) or NULL. */
+int cddpm_op_gn_coef(cddpm_handle h, const float* src0_dev, int C0, const float* src1_dev, int C1,
+                     const float* gamma_host, const float* beta_host, const float* film_dev,
+                     float* coef_dev, int B, int HW, void* stream);
+
+/* standalone attention core on qkv NHWC [B,N,3C] (q | k | v, heads = contiguous groups of head_channels):
+ * out [B,N,C] = softmax(q k^T / sqrt(head_channels)) v  (QKVAttention, OpenAI_Unet.py:457-476). */
+int cddpm_op_attention(cddpm_handle h, const float* qkv_dev, float* out_dev, int B, int N, int C, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CDDPM_H */

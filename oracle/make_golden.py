@@ -1,0 +1,129 @@
+"""ORACLE tooling -- build-container only: run the REFERENCE (imported from /root/reference by
+oracle/ref_harness.py) on seeded synthetic inputs and store its outputs under tests/golden/.
+
+    python oracle/make_golden.py            # all cases (~5 min on 8 cores)
+    python oracle/make_golden.py --quick    # skip the two 128x128 loops
+
+Inputs are NOT stored: weights, cond, x_T and z_t are regenerated from seeds by the package's
+counter RNG (synth.py), so the fixtures stay < 1 MB. Every fixture holds reference OUTPUTS only.
+tests/test_oracle_golden.py then pins oracle/cddpm_oracle.py against these files without the reference.
+"""
+from __future__ import annotations
+
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+synth = importlib.import_module("conditioned-diffusion-models-uad_amd.synth")
+import cddpm_oracle as O  # noqa: E402
+import ref_harness as R  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+SEED_W, SEED_COND, SEED_XT, SEED_Z = 0, 1, 2, 3   # weights 0, cond 1, x_T 2, z 3
+
+
+def loop_case(sd, H, W, B, timesteps, start_t, slice0=0):
+    """reference p_sample_loop with injected draws; returns (reference output, oracle max|diff|)."""
+    _model, diff = R.build_reference(sd, image_size=(H, W), timesteps=timesteps)
+    T = timesteps if start_t == 0 else start_t
+    cond = torch.from_numpy(synth.synth_cond(SEED_COND, slice0, B))
+    xT = torch.from_numpy(synth.noise_xT(SEED_XT, slice0, B, H, W))
+    zs = {t: torch.from_numpy(synth.noise_z(SEED_Z, t, slice0, B, H, W)) for t in range(1, T)}
+    draws = [xT] + [zs[t] for t in range(T - 1, 0, -1)]
+    with R.injected_randn(draws):
+        ref = diff.p_sample_loop((B, 1, H, W), cond=cond, start_t=start_t)
+    buf = O.schedule_buffers(timesteps)
+    ora = O.p_sample_loop(xT, cond, sd, buf, lambda t: zs[t], start_t=start_t)
+    return ref.numpy(), float((ref - ora).abs().max())
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--quick", action="store_true")
+    args = ap.parse_args()
+    os.makedirs(GOLD, exist_ok=True)
+    torch.manual_seed(0)
+    manifest = {"torch": torch.__version__, "threads": torch.get_num_threads(), "cases": {}}
+
+    sd_np = synth.synth_state_dict(SEED_W)
+    sd = O.to_torch_sd(sd_np)
+
+    # --- S1 schedule buffers, T = 1000 and T = 50 (cond_DDPM.py:336-377)
+    for T in (1000, 50):
+        _m, diff = R.build_reference(sd, image_size=(32, 32), timesteps=T)
+        names = list(O.schedule_buffers(T).keys())
+        np.savez_compressed(os.path.join(GOLD, f"schedule_T{T}.npz"), **{n: getattr(diff, n).numpy() for n in names})
+        manifest["cases"][f"schedule_T{T}"] = {"buffers": names}
+
+    # --- U1 timestep embedding (util.py:151-171)
+    sys.path.insert(0, R.REF_ROOT)
+    from src.models.LDM.modules.diffusionmodules.util import timestep_embedding as ref_temb  # type: ignore
+    ts = torch.tensor([0, 1, 2, 250, 500, 998, 999], dtype=torch.long)
+    np.savez_compressed(os.path.join(GOLD, "timestep_embedding.npz"), t=ts.numpy(), emb=ref_temb(ts, 128).numpy())
+
+    # --- U0 full UNet forward, several geometries
+    for (B, H, W) in ((2, 32, 32), (1, 64, 96), (1, 96, 96), (1, 128, 128)):
+        model, _d = R.build_reference(sd, image_size=(H, W), timesteps=1000)
+        x = torch.from_numpy(synth.noise_xT(SEED_XT, 0, B, H, W))
+        cond = torch.from_numpy(synth.synth_cond(SEED_COND, 0, B))
+        outs, errs = {}, {}
+        tlist = (0, 500, 999) if H == 32 else (500,)
+        for t in tlist:
+            tt = torch.full((B,), t, dtype=torch.long)
+            with torch.no_grad():
+                r = model(x, tt, cond=cond)
+            o = O.unet_forward(x, tt, cond, sd)
+            outs[f"t{t}"] = r.numpy()
+            errs[f"t{t}"] = float((r - o).abs().max())
+        # per-sample different t (what p_losses feeds, cond_DDPM.py:651)
+        if B > 1:
+            tt = torch.tensor([123, 877][:B], dtype=torch.long)
+            with torch.no_grad():
+                outs["tmixed"] = model(x, tt, cond=cond).numpy()
+        np.savez_compressed(os.path.join(GOLD, f"unet_fwd_B{B}_{H}x{W}.npz"), **outs)
+        manifest["cases"][f"unet_fwd_B{B}_{H}x{W}"] = {"oracle_vs_reference_maxabs": errs}
+        print("unet_fwd", B, H, W, errs, flush=True)
+
+    # --- f1 single-step reconstruction GaussianDiffusion.forward -> p_losses (cond_DDPM.py:565-655)
+    B, H, W = 2, 32, 32
+    _m, diff = R.build_reference(sd, image_size=(H, W), timesteps=1000)
+    x01 = torch.from_numpy(synth.synth_slices(SEED_XT, 0, B, H, W))
+    cond = torch.from_numpy(synth.synth_cond(SEED_COND, 0, B))
+    noise = torch.from_numpy(synth.noise_z(SEED_Z, 0, 0, B, H, W))
+    with torch.no_grad():
+        loss, reco = diff(x01, t=499, cond=cond, noise=noise)
+    ol, orc = O.p_losses_recon(x01, torch.full((B,), 499, dtype=torch.long), cond, noise, sd, O.schedule_buffers(1000))
+    np.savez_compressed(os.path.join(GOLD, "p_losses_B2_32x32_t499.npz"), loss=loss.numpy(), reco=reco.numpy())
+    manifest["cases"]["p_losses_B2_32x32_t499"] = {"oracle_vs_reference_maxabs": float((reco - orc).abs().max()),
+                                                   "loss_absdiff": float((loss - ol).abs())}
+
+    # --- S2 reverse loops
+    loops = [("loop_B2_32x32_T1000_start8", dict(H=32, W=32, B=2, timesteps=1000, start_t=8)),
+             ("loop_B2_32x32_T50_start0", dict(H=32, W=32, B=2, timesteps=50, start_t=0)),
+             ("loop_B3_32x48_T1000_start5_slice7", dict(H=32, W=48, B=3, timesteps=1000, start_t=5, slice0=7))]
+    if not args.quick:
+        loops += [("loop_cfg1_B4_128x128_T50_start0", dict(H=128, W=128, B=4, timesteps=50, start_t=0)),
+                  ("loop_B1_128x128_T1000_start50", dict(H=128, W=128, B=1, timesteps=1000, start_t=50))]
+    for name, kw in loops:
+        t0 = time.time()
+        ref, err = loop_case(sd, **kw)
+        np.savez_compressed(os.path.join(GOLD, name + ".npz"), out=ref)
+        manifest["cases"][name] = dict(kw, oracle_vs_reference_maxabs=err, seconds=round(time.time() - t0, 1),
+                                       seeds=dict(weights=SEED_W, cond=SEED_COND, xT=SEED_XT, z=SEED_Z))
+        print(name, "oracle-vs-ref", err, f"{time.time() - t0:.1f}s", flush=True)
+
+    with open(os.path.join(GOLD, "MANIFEST.json"), "w") as f:
+        json.dump(manifest, f, indent=1, sort_keys=True)
+
+
+if __name__ == "__main__":
+    main()
