@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""bench.py -- reconstructed 128x128 slices/sec @ T=1000 of the cDDPM reverse-diffusion path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--size S] [--no-cpu]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): the reference UNet configuration (43.87 M parameters, fp32), a batch of
+64 synthetic single-channel 128x128 slices per GPU, T = 1000. One "step" = one reverse step p_sample
+(UNet forward + posterior update with on-device Philox noise) over the whole batch, executed by
+cddpm_p_sample of libcddpm_hip.so. A slice needs T such steps, every step does identical work, so
+    value [slices/s] = n_gpus * B / (T * seconds_per_step)
+with seconds_per_step from EXACTLY K timed steps (barrier + synchronize on both sides, max over ranks).
+Weights, context vectors and x_T are synthetic (counter RNG, synth.py) and resident in HBM before timing.
+
+Extra objects on the JSON line:
+  roofline      dominant kernel = the fused fp32-MFMA 3x3 convolution: algorithmic FLOPs of its launches /
+                their HIP-event durations (events recorded on the launch stream inside the timed steps),
+                against the 157.3 TFLOP/s dense fp32 MFMA peak of MI355X_MICROARCH.md.
+  cpu_baseline  oracle/cddpm_oracle.py (torch CPU restatement of the reference path, "port") timed on this
+                host's cores on a bounded sample (B=4, a few p_sample steps), rank 0 at N=1 only.
+"""
+from __future__ import annotations
+
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+PKG = "conditioned-diffusion-models-uad_amd"
+T_TOTAL = 1000
+PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense fp32 MFMA peak (= fp32 vector peak)
+PEAK_HBM_TBPS = 8.0
+FLOP_PER_SLICE_STEP = {128: 265.6e9, 96: 149.1e9, 256: 1075.1e9}
+BYTES_PER_SLICE_STEP_128 = 1.043e9                                    # SURVEY.md 8(d), fused-kernel model
+
+
+def cpu_baseline(synth, size: int, steps: int = 4, batch: int = 4):
+    """time the oracle (CPU restatement) on this host: bounded sample, NOT the thing shipped or measured"""
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import cddpm_oracle as O
+    sd = O.to_torch_sd(synth.synth_state_dict(0))
+    buf = O.schedule_buffers(T_TOTAL)
+    x = torch.from_numpy(synth.noise_xT(2, 0, batch, size, size))
+    cond = torch.from_numpy(synth.synth_cond(1, 0, batch))
+    threads = torch.get_num_threads()
+    times = []
+    with torch.no_grad():
+        for i in range(steps + 1):
+            t = T_TOTAL - 1 - i
+            z = torch.from_numpy(synth.noise_z(3, t, 0, batch, size, size))
+            t0 = time.perf_counter()
+            x = O.p_sample(x, t, cond, sd, buf, z)
+            times.append(time.perf_counter() - t0)
+    per_step = sorted(times[1:])[len(times[1:]) // 2]     # median after one warm-up
+    return {"value": batch / (T_TOTAL * per_step), "unit": "slices/s", "cores": threads, "kind": "port",
+            "sample": f"oracle p_sample, B={batch}, {size}x{size}, 1 warm-up + {steps} timed steps (median), "
+                      f"extrapolated x{T_TOTAL} steps; host has {os.cpu_count()} logical CPUs",
+            "s_per_slice_step": per_step / batch}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=64, help="slices per GPU (configs[1]: 64)")
+    ap.add_argument("--size", type=int, default=128)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-profile", action="store_true", help="no per-kernel HIP events in the timed steps")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (the path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)   # RCCL
+
+    synth = importlib.import_module(PKG + ".synth")
+    sched = importlib.import_module(PKG + ".schedule")
+    eng_mod = importlib.import_module(PKG + ".engine")
+
+    B, S = args.batch, args.size
+    slice0 = rank * B                                   # weak scaling: every rank owns B distinct slices
+    eng = eng_mod.CddpmEngine(timesteps=T_TOTAL, max_batch=B, max_h=S, max_w=S, device=dev)
+    eng.load_weights(synth.synth_state_dict(0))
+    eng.set_schedule(sched.schedule_buffers(T_TOTAL))
+    cond = torch.from_numpy(synth.synth_cond(1, slice0, B)).to(dev)
+    x = eng.noise_fill(B, S, S, seed=2, stream_id=synth.STREAM_XT, slice0=slice0)   # x_T on device
+    eng.prepare_cond(cond, B)
+
+    t = T_TOTAL - 1
+    for _ in range(args.warmup):
+        eng.p_sample_(x, t, seed=3, slice0=slice0)
+        t -= 1
+    eng.set_profiling(not args.no_profile)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.p_sample_(x, t, seed=3, slice0=slice0)
+        t -= 1
+    torch.cuda.synchronize(dev)
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    eng.set_profiling(False)
+    prof = None if args.no_profile else eng.get_profile()
+
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        # the path's one collective: gather of the per-rank results (here: the current state) over xGMI
+        g0 = time.perf_counter()
+        gathered = torch.empty((world * B, 1, S, S), dtype=torch.float32, device=dev)
+        dist.all_gather_into_tensor(gathered, x)
+        torch.cuda.synchronize(dev)
+        gather_ms = (time.perf_counter() - g0) * 1e3
+    else:
+        gather_ms = 0.0
+    finite = bool(torch.isfinite(x).all().item())
+
+    s_per_step = elapsed / args.steps
+    value = world * B / (T_TOTAL * s_per_step)
+    flop_step = FLOP_PER_SLICE_STEP.get(S, 265.6e9 * (S / 128.0) ** 2) * B
+    out = {
+        "metric": "reconstructed 128x128 slices/sec @ T=1000" if S == 128 else f"reconstructed {S}x{S} slices/sec @ T=1000",
+        "value": value, "unit": "slices/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": s_per_step * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"configs[1]: reference UNet (43.87M params, fp32), {B}x1x{S}x{S} slices per GPU, "
+                               f"T={T_TOTAL}, p_sample steps t={T_TOTAL - 1 - args.warmup}..{t + 1}; value = n_gpus*B/(T*s_per_step)",
+                   "batch_per_gpu": B, "global_batch": world * B, "size": S, "T": T_TOTAL,
+                   "parallelism": f"slice-sharded x{world}, no collective in the loop, one all_gather at the end",
+                   "gather_ms": gather_ms, "finite": finite,
+                   "whole_step_tflops": flop_step / s_per_step / 1e12,
+                   "whole_step_frac_of_fp32_peak": flop_step / s_per_step / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                   "hbm_frac_fused_model": (BYTES_PER_SLICE_STEP_128 * (S / 128.0) ** 2 * B + 0.1755e9) / s_per_step / (PEAK_HBM_TBPS * 1e12)},
+    }
+    if prof is not None:
+        c3 = prof["conv3x3_mfma"]
+        ach = c3["flops"] / (c3["ms"] * 1e-3) / 1e12 if c3["ms"] > 0 else 0.0
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "conv3x3_hbm_traffic.json")
+        if os.path.exists(tfile):
+            try:
+                traffic = json.load(open(tfile)).get("bytes_per_launch")
+            except Exception:
+                traffic = None
+        out["roofline"] = {"bound": "mfma", "kernel": "conv_mfma_kernel<9> (fused GN/FiLM/SiLU + 3x3 conv + skip, fp32 MFMA)",
+                           "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                           "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
+                           "launches": c3["launches"], "avg_launch_ms": c3["ms"] / max(1, c3["launches"]),
+                           "flops_per_launch": c3["flops"] / max(1, c3["launches"]),
+                           "algorithmic_bytes_per_launch": c3["bytes"] / max(1, c3["launches"]),
+                           "share_of_step_time": c3["ms"] / (elapsed * 1e3)}
+        out["kernel_classes"] = {k: {"ms_per_step": v["ms"] / args.steps, "launches_per_step": v["launches"] / args.steps,
+                                     "tflops": (v["flops"] / (v["ms"] * 1e-3) / 1e12) if v["ms"] > 0 else 0.0,
+                                     "algorithmic_GBps": (v["bytes"] / (v["ms"] * 1e-3) / 1e9) if v["ms"] > 0 else 0.0}
+                                 for k, v in prof.items()}
+    if rank == 0 and world == 1 and not args.no_cpu:
+        out["cpu_baseline"] = cpu_baseline(synth, S)
+        out["config"]["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
+    eng.close()
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

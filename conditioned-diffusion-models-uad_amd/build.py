@@ -1,0 +1,61 @@
+"""Build csrc/*.hip into csrc/libcddpm_hip.so for gfx950 with hipcc (in-tree, no JIT cache).
+
+hipcc cross-compiles without a GPU, so this runs in the build container; the .so travels to the GPU box.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+SOURCES = ["conv_mfma.hip", "norm_kernels.hip", "small_kernels.hip", "attention.hip", "cddpm_api.hip"]
+LIB = os.path.join(CSRC, "libcddpm_hip.so")
+ARCH = "gfx950"
+
+
+def _hipcc() -> str:
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found (need ROCm); cannot build libcddpm_hip.so")
+    return exe
+
+
+def lib_is_current() -> bool:
+    if not os.path.exists(LIB):
+        return False
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, s) for s in SOURCES + ["kernels.h"]]
+    deps.append(os.path.join(os.path.dirname(os.path.dirname(CSRC)), "include", "cddpm.h"))
+    return all(os.path.getmtime(d) <= t for d in deps if os.path.exists(d))
+
+
+def build_lib(force: bool = False, verbose: bool = False) -> str:
+    if not force and lib_is_current():
+        return LIB
+    hipcc = _hipcc()
+    flags = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+    objs = []
+
+    def compile_one(src):
+        obj = os.path.join(CSRC, src.replace(".hip", ".o"))
+        cmd = [hipcc, *flags, "-c", os.path.join(CSRC, src), "-o", obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {src}:\n{r.stderr}")
+        if verbose and r.stderr.strip():
+            print(r.stderr, file=sys.stderr)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(5, os.cpu_count() or 1)) as ex:
+        objs = list(ex.map(compile_one, SOURCES))
+    r = subprocess.run([hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB, *objs], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc link failed:\n{r.stderr}")
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build_lib(force="--force" in sys.argv, verbose=True))

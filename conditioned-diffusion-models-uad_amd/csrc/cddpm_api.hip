@@ -99,6 +99,12 @@ struct cddpm_ctx {
     float* coef = nullptr;
     float *scratch0 = nullptr, *scratch1 = nullptr;   // [max(T,Bmax)][half] for the embedding MLPs
     int max_nsplit = 0;
+
+    // optional per-kernel-class timing with HIP events on the launch stream (cddpm_set_profiling)
+    struct ProfRec { hipEvent_t a, b; int cls; double flops; double bytes; };
+    bool profiling = false;
+    std::vector<ProfRec> prof;
+    std::vector<hipEvent_t> ev_pool;
 };
 
 namespace {
@@ -111,6 +117,44 @@ int fail(cddpm_ctx* h, const char* fmt, ...) {
     va_end(ap);
     if (h) h->err = buf; else g_create_error = buf;
     return -1;
+}
+
+enum ProfClass { PC_CONV3 = 0, PC_CONV1 = 1, PC_ATTN = 2, PC_GN = 3, PC_OTHER = 4, PC_COUNT = 5 };
+
+struct Prof {
+    cddpm_ctx* h; hipStream_t s; cddpm_ctx::ProfRec r; bool on;
+    static hipEvent_t ev(cddpm_ctx* h) {
+        if (!h->ev_pool.empty()) { hipEvent_t e = h->ev_pool.back(); h->ev_pool.pop_back(); return e; }
+        hipEvent_t e = nullptr;
+        (void)hipEventCreate(&e);
+        return e;
+    }
+    Prof(cddpm_ctx* h_, int cls, double flops, double bytes, hipStream_t s_) : h(h_), s(s_), on(h_->profiling) {
+        if (!on) return;
+        r.cls = cls; r.flops = flops; r.bytes = bytes; r.a = ev(h); r.b = ev(h);
+        (void)hipEventRecord(r.a, s);
+    }
+    ~Prof() {
+        if (!on) return;
+        (void)hipEventRecord(r.b, s);
+        h->prof.push_back(r);
+    }
+};
+
+double conv_flops(const ConvArgs& a) {
+    return 2.0 * a.B * a.H * a.W * a.Cout * ((double)(a.C0 + a.C1) * a.taps + a.S0 + a.S1);
+}
+// algorithmic bytes of one fused conv launch: every input read once, output written once, weights once
+double conv_bytes(const ConvArgs& a) {
+    const double px = (double)a.B * a.H * a.W, spx = (double)a.B * a.srcH * a.srcW;
+    double b = spx * (a.C0 + a.C1) + px * (a.S0 + a.S1) + px * a.Cout;
+    if (a.res) b += (a.res_up ? px / 4 : px) * a.Cout;
+    b += (double)a.Cout * ((double)(a.C0 + a.C1) * a.taps + a.S0 + a.S1);
+    return 4.0 * b;
+}
+void conv_launch(cddpm_ctx* h, const ConvArgs& a, hipStream_t s) {
+    Prof p(h, a.taps == 9 ? PC_CONV3 : PC_CONV1, conv_flops(a), conv_bytes(a), s);
+    launch_conv(a, s);
 }
 
 #define HIPCHECK(h, call)                                                                      \
@@ -389,6 +433,7 @@ void gn_coef(cddpm_ctx* h, const float* x0, int C0, const float* x1, int C1, int
              bool film, int eoff, hipStream_t s) {
     const int Ct = C0 + C1;
     const int ns = gn_nsplit(B, HW);
+    Prof p(h, PC_GN, 0.0, 4.0 * B * (double)HW * Ct, s);
     launch_gn_partial(x0, C0, Ct, 0, B, HW, ns, h->gn_part, s);
     if (x1) launch_gn_partial(x1, C1, Ct, C0, B, HW, ns, h->gn_part, s);
     launch_gn_finalize(h->gn_part, ns, Ct, B, HW, nw.gamma, nw.beta, film ? h->tab : nullptr, h->cpart, h->sumE, eoff,
@@ -410,7 +455,10 @@ void run_res(cddpm_ctx* h, const ResW& r, const float* x0, int C0, const float* 
     int res_up = 0;
     if (r.down) {
         Ho = H / 2; Wo = W / 2;
-        launch_pool_act(x0, h->coef, h->bufP0, h->bufP1, B, H, W, C0, s);
+        {
+            Prof pp(h, PC_OTHER, 0.0, 4.0 * B * (double)H * W * C0 * 1.5, s);
+            launch_pool_act(x0, h->coef, h->bufP0, h->bufP1, B, H, W, C0, s);
+        }
         a.src0 = h->bufP0; a.C0 = C0; a.srcH = Ho; a.srcW = Wo;
         resid = h->bufP1;
     } else if (r.up) {
@@ -421,7 +469,7 @@ void run_res(cddpm_ctx* h, const ResW& r, const float* x0, int C0, const float* 
         a.src0 = x0; a.C0 = C0; a.src1 = x1; a.C1 = C1; a.srcH = H; a.srcW = W; a.coef = h->coef; a.silu = 1;
     }
     a.H = Ho; a.W = Wo;
-    launch_conv(a, s);
+    conv_launch(h, a, s);
     // out_layers: GroupNorm * (1 + scale) + shift -> SiLU -> conv, + skip
     gn_coef(h, h->bufH, r.Cout, nullptr, 0, B, Ho * Wo, r.gn2, true, r.eoff, s);
     ConvArgs c;
@@ -434,7 +482,7 @@ void run_res(cddpm_ctx* h, const ResW& r, const float* x0, int C0, const float* 
     } else {
         c.res = resid; c.res_up = res_up;
     }
-    launch_conv(c, s);
+    conv_launch(h, c, s);
 }
 
 // AttentionBlock (OpenAI_Unet.py:386-394)
@@ -446,14 +494,17 @@ void run_attn(cddpm_ctx* h, const AttnW& w, const float* x, float* dst, int B, i
     a.B = B; a.H = H; a.W = W; a.Cout = 3 * w.C; a.taps = 1;
     a.src0 = x; a.C0 = w.C; a.srcH = H; a.srcW = W; a.coef = h->coef; a.silu = 0;
     a.wpk = w.qkv.wpk; a.bias = w.qkv.bias; a.out = h->qkvbuf;
-    launch_conv(a, s);
-    launch_attention(h->qkvbuf, h->attbuf, B, N, w.C, s);
+    conv_launch(h, a, s);
+    {
+        Prof pa(h, PC_ATTN, 4.0 * B * (double)N * N * w.C, 4.0 * B * (double)N * 4 * w.C, s);
+        launch_attention(h->qkvbuf, h->attbuf, B, N, w.C, s);
+    }
     ConvArgs p;
     zero_conv_args(p);
     p.B = B; p.H = H; p.W = W; p.Cout = w.C; p.taps = 1;
     p.src0 = h->attbuf; p.C0 = w.C; p.srcH = H; p.srcW = W;
     p.wpk = w.proj.wpk; p.bias = w.proj.bias; p.res = x; p.out = dst;
-    launch_conv(p, s);
+    conv_launch(h, p, s);
 }
 
 int check_call(cddpm_ctx* h, int B, int H, int W) {
@@ -485,8 +536,10 @@ int forward_impl(cddpm_ctx* h, const float* x, float* out, int B, int H, int W, 
         else { dst = pp[ppi]; ppi ^= 1; }
         const int Hc = H / curds, Wc = W / curds;
         switch (op.kind) {
-            case OP_IN:
+            case OP_IN: {
+                Prof pi(h, PC_OTHER, 18.0 * B * H * W * h->d.model_channels, 4.0 * B * (double)H * W * (h->d.model_channels + 1), s);
                 launch_conv_in1(x, h->in_w, h->in_b, dst, B, H, W, h->d.model_channels, s);
+            }
                 curC = h->d.model_channels;
                 break;
             case OP_RES: {
@@ -512,6 +565,7 @@ int forward_impl(cddpm_ctx* h, const float* x, float* out, int B, int H, int W, 
                 break;
             case OP_HEAD: {
                 gn_coef(h, cur, curC, nullptr, 0, B, H * W, h->out_norm, false, 0, s);
+                Prof ph(h, PC_OTHER, 18.0 * B * H * W * curC, 4.0 * B * (double)H * W * (curC + 19), s);
                 launch_head_dots(cur, h->coef, h->head_w9, h->headP, B, H * W, curC, s);
                 launch_head_gather(h->headP, h->head_bias, out, B, H, W, s);
                 dst = nullptr;
@@ -581,6 +635,8 @@ void cddpm_destroy(cddpm_handle h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     for (void* p : h->allocs) (void)hipFree(p);
+    for (auto& r : h->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
     delete h;
 }
 
@@ -754,6 +810,34 @@ int cddpm_unet_forward(cddpm_handle h, const float* x_dev, const int32_t* t_dev,
     return forward_impl(h, x_dev, out_dev, B, H, W, s);
 }
 
+static int step_once(cddpm_ctx* h, float* img, const float* z_dev, uint64_t seed, uint64_t slice0, int t, int finalize,
+                     int B, int H, int W, hipStream_t s) {
+    launch_fill_int(h->d_t, B, t, s);
+    if (forward_impl(h, img, h->model_out, B, H, W, s)) return -1;
+    StepArgs a;
+    a.x = img; a.model_out = h->model_out; a.t_dev = h->d_t;
+    a.coef1 = h->sched[0]; a.coef2 = h->sched[1]; a.logvar = h->sched[2];
+    a.sqrt_recip = h->sched[3]; a.sqrt_recipm1 = h->sched[4];
+    a.objective = h->objective;
+    a.noise = z_dev;
+    a.seed = seed; a.slice0 = slice0; a.t_for_rng = t;
+    a.B = B; a.HW = H * W; a.finalize = finalize;
+    launch_step(a, s);
+    return 0;
+}
+
+int cddpm_p_sample(cddpm_handle h, float* img, const float* z_dev, uint64_t seed, uint64_t slice0, int t, int B, int H,
+                   int W, void* stream) {
+    if (check_call(h, B, H, W)) return -1;
+    if (!img) return fail(h, "img_inout_dev is NULL");
+    if (t < 0 || t >= h->d.timesteps) return fail(h, "t=%d outside [0, %d)", t, h->d.timesteps);
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHECK(h, hipSetDevice(h->device));
+    if (step_once(h, img, z_dev, seed, slice0, t, 0, B, H, W, s)) return -1;
+    HIPCHECK(h, hipGetLastError());
+    return 0;
+}
+
 int cddpm_reverse(cddpm_handle h, float* img, const float* noise_dev, uint64_t seed, uint64_t slice0, int t_start, int B,
                   int H, int W, void* stream) {
     if (check_call(h, B, H, W)) return -1;
@@ -761,20 +845,10 @@ int cddpm_reverse(cddpm_handle h, float* img, const float* noise_dev, uint64_t s
     if (t_start < 1 || t_start > h->d.timesteps) return fail(h, "t_start=%d outside [1, %d]", t_start, h->d.timesteps);
     hipStream_t s = (hipStream_t)stream;
     HIPCHECK(h, hipSetDevice(h->device));
-    const int HW = H * W;
-    for (int t = t_start - 1; t >= 0; --t) {
-        launch_fill_int(h->d_t, B, t, s);
-        if (forward_impl(h, img, h->model_out, B, H, W, s)) return -1;
-        StepArgs a;
-        a.x = img; a.model_out = h->model_out; a.t_dev = h->d_t;
-        a.coef1 = h->sched[0]; a.coef2 = h->sched[1]; a.logvar = h->sched[2];
-        a.sqrt_recip = h->sched[3]; a.sqrt_recipm1 = h->sched[4];
-        a.objective = h->objective;
-        a.noise = noise_dev ? noise_dev + (size_t)t * B * HW : nullptr;
-        a.seed = seed; a.slice0 = slice0; a.t_for_rng = t;
-        a.B = B; a.HW = HW; a.finalize = (t == 0);
-        launch_step(a, s);
-    }
+    const size_t HW = (size_t)H * W;
+    for (int t = t_start - 1; t >= 0; --t)
+        if (step_once(h, img, noise_dev ? noise_dev + (size_t)t * B * HW : nullptr, seed, slice0, t, t == 0, B, H, W, s))
+            return -1;
     HIPCHECK(h, hipGetLastError());
     return 0;
 }
@@ -803,6 +877,29 @@ int cddpm_q_sample(cddpm_handle h, const float* x01_dev, const float* noise_dev,
     else launch_fill_int(h->d_t, B, t_uniform, s);
     launch_q_sample(x01_dev, noise_dev, h->d_t, h->qs_sa, h->qs_s1, out_dev, B, H * W, s);
     HIPCHECK(h, hipGetLastError());
+    return 0;
+}
+
+int cddpm_set_profiling(cddpm_handle h, int on) {
+    if (!h) return -1;
+    h->profiling = on != 0;
+    return 0;
+}
+
+int cddpm_get_profile(cddpm_handle h, int ncls, double* ms, double* flops, double* bytes, int64_t* launches) {
+    if (!h) return -1;
+    if (ncls != PC_COUNT) return fail(h, "cddpm_get_profile: ncls must be %d", (int)PC_COUNT);
+    HIPCHECK(h, hipSetDevice(h->device));
+    HIPCHECK(h, hipDeviceSynchronize());
+    for (int i = 0; i < PC_COUNT; ++i) { ms[i] = 0; flops[i] = 0; bytes[i] = 0; launches[i] = 0; }
+    for (auto& r : h->prof) {
+        float t = 0.f;
+        HIPCHECK(h, hipEventElapsedTime(&t, r.a, r.b));
+        ms[r.cls] += t; flops[r.cls] += r.flops; bytes[r.cls] += r.bytes; launches[r.cls] += 1;
+        h->ev_pool.push_back(r.a);
+        h->ev_pool.push_back(r.b);
+    }
+    h->prof.clear();
     return 0;
 }
 

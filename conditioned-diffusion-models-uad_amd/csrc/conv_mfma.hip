@@ -26,8 +26,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float v4f __attribute__((ext_vector_type(4)));   // native vector: stays in registers (HIP's float4 struct arrays may not)
 
 __device__ __forceinline__ float silu_f(float v) {
-    // v * sigmoid(v); v_exp_f32 + v_rcp_f32 (<= 2 ulp), no overflow issue: exp(+large) = inf -> rcp = 0
-    return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));
+    // v * sigmoid(v); accurate expf (<= 1 ulp) + v_rcp_f32 (1 ulp); exp(+large) = inf -> rcp = 0, no NaN
+    return v * __builtin_amdgcn_rcpf(1.0f + expf(-v));
 }
 
 template <int TAPS>
@@ -149,13 +149,17 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
         }
     };
 
-    f32x16 acc[2][2];
+    // Two-level accumulation: `acc` collects one 32-channel chunk (<= 9 taps x 32 = 288 products per chain),
+    // `tot` sums the chunks. A single K-long fp32 fmaf chain (K up to 4608 + 512) carries ~sqrt(K/2) ulp of
+    // rounding noise, about 3x what the reference's blocked CPU convolution shows against fp64; splitting the
+    // chain brings this kernel to the same level (measured in tests/test_gpu_unet.py, fp64 yardstick).
+    f32x16 acc[2][2], tot[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; tot[i][j][r] = 0.f; }
 
     // B operand (weights) LDS offsets: row j = cout within the 128 block
     int boff[2], bsw[2];
@@ -224,6 +228,14 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
             compute(main_seg ? t : (TAPS / 2), buf);   // skip segment: centre tap
             buf ^= 1;
         }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                tot[i][j] += acc[i][j];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            }
     }
 
     // ---- epilogue: D row = pixel (r&3) + 8 (r>>2) + 4 lh, D col = cout li
@@ -239,7 +251,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
             for (int r = 0; r < 16; ++r) {
                 const int x = x0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 if (x < a.W) {
-                    float v = acc[mt][nt][r] + bias;
+                    float v = tot[mt][nt][r] + bias;
                     if (a.res) {
                         const size_t rp = a.res_up ? ((size_t)(b * (a.H >> 1) + (y >> 1)) * (a.W >> 1) + (x >> 1))
                                                    : ((size_t)(b * a.H + y) * a.W + x);

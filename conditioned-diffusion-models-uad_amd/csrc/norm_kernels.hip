@@ -16,12 +16,11 @@
 namespace cddpm {
 
 int gn_nsplit(int B, int HW) {
-    // aim at >= ~2048 workgroups, at least 64 pixels each
-    int ppb = (int)(((long long)HW * B + 2047) / 2048);
-    if (ppb < 64) ppb = 64;
-    int ns = (HW + ppb - 1) / ppb;
-    if (ns < 1) ns = 1;
-    return ns;
+    // The pixel-range split depends on the image size ONLY (never on the batch): a slice's statistics are
+    // then summed in the same order whatever batch or rank it sits in -> sharded runs are bitwise identical.
+    (void)B;
+    const int ppb = (HW >= 4096) ? 256 : 64;
+    return (HW + ppb - 1) / ppb;
 }
 
 __global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict__ src, int C, int Ctot, int coff,

@@ -5,7 +5,7 @@
 
 namespace cddpm {
 
-__device__ __forceinline__ float silu_s(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
+__device__ __forceinline__ float silu_s(float v) { return v * __builtin_amdgcn_rcpf(1.0f + expf(-v)); }
 
 // ------------------------------------------------------------------------------------------------
 // input_blocks.0: Conv2d(1 -> C, 3x3, pad 1)  (src/models/modules/OpenAI_Unet.py:606-612)

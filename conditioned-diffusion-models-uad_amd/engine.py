@@ -1,0 +1,293 @@
+"""Thin Python owner of one libcddpm_hip handle: PyTorch-ROCm tensors in, raw pointers out.
+
+PyTorch is used for device memory, the current HIP stream and (elsewhere) torch.distributed only;
+every FLOP of the path runs in csrc/*.hip through the C ABI of include/cddpm.h.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Mapping, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+
+OBJECTIVES = {"pred_x0": 0, "pred_noise": 1}
+
+
+def _stream_ptr(device) -> int:
+    return int(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _check_dev(t: torch.Tensor, name: str, device) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError(f"{name} must be a tensor on a HIP device (got {type(t).__name__} on "
+                           f"{getattr(t, 'device', None)}); the HIP path has no CPU fallback")
+    if t.device != device:
+        raise RuntimeError(f"{name} lives on {t.device}, the engine on {device}")
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"{name} must be float32 (got {t.dtype}); the path computes in fp32 only")
+    return t.contiguous()
+
+
+class CddpmEngine:
+    """One device's packed UNet + schedule tables + workspace (cddpm_create .. cddpm_destroy)."""
+
+    def __init__(self, *, model_channels=128, channel_mult=(1, 2, 2), num_res_blocks=3,
+                 attention_resolutions=(3, 6, 12), head_channels=64, cond_dim=128, timesteps=1000,
+                 max_batch=1, max_h=128, max_w=128, device=None, in_channels=1, out_channels=1):
+        self.lib = _lib.load_library()
+        if not torch.cuda.is_available():
+            raise RuntimeError("no HIP device visible: the cDDPM HIP path needs an MI355X (gfx950); there is no CPU fallback")
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        d = _lib.UnetDesc()
+        d.in_channels, d.out_channels, d.model_channels = in_channels, out_channels, model_channels
+        d.num_levels = len(channel_mult)
+        for i, m in enumerate(channel_mult):
+            d.channel_mult[i] = int(m)
+        d.num_res_blocks = num_res_blocks
+        d.num_attention_resolutions = len(attention_resolutions)
+        for i, a in enumerate(attention_resolutions):
+            d.attention_resolutions[i] = int(a)
+        d.head_channels, d.cond_dim, d.timesteps = head_channels, int(cond_dim or 0), timesteps
+        d.max_batch, d.max_h, d.max_w = max_batch, max_h, max_w
+        self.desc = d
+        self.timesteps = timesteps
+        self.cond_dim = int(cond_dim or 0)
+        self.max_batch, self.max_h, self.max_w = max_batch, max_h, max_w
+        self._h = C.c_void_p()
+        rc = self.lib.cddpm_create(C.byref(self._h), C.byref(d), self.device.index)
+        if rc != 0:
+            msg = self.lib.cddpm_last_error(None).decode()
+            self._h = None
+            raise RuntimeError(f"cddpm_create failed: {msg}")
+        self._keep = []   # tensors whose pointers the library may still read (taps)
+
+    # ------------------------------------------------------------------ lifetime / errors
+    def close(self):
+        if getattr(self, "_h", None):
+            torch.cuda.synchronize(self.device)
+            self.lib.cddpm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc: int, what: str):
+        if rc != 0:
+            raise RuntimeError(f"{what} failed: {self.lib.cddpm_last_error(self._h).decode()}")
+
+    # ------------------------------------------------------------------ setup
+    def weight_names(self):
+        n = self.lib.cddpm_num_weights(self._h)
+        return [(self.lib.cddpm_weight_name(self._h, i).decode(), int(self.lib.cddpm_weight_numel(self._h, i)))
+                for i in range(n)]
+
+    def load_weights(self, state_dict: Mapping[str, object], prefix: str = ""):
+        """state_dict: reference names (optionally under `prefix`, e.g. 'diffusion.model.') -> tensor/ndarray."""
+        names, arrs = [], []
+        for name, _numel in self.weight_names():
+            key = prefix + name
+            if key not in state_dict:
+                raise KeyError(f"state_dict has no '{key}'")
+            v = state_dict[key]
+            if isinstance(v, torch.Tensor):
+                v = v.detach().to("cpu", torch.float32).contiguous().numpy()
+            v = np.ascontiguousarray(v, dtype=np.float32)
+            names.append(name.encode())
+            arrs.append(v)
+        n = len(names)
+        c_names = (C.c_char_p * n)(*names)
+        c_ptrs = (C.c_void_p * n)(*[a.ctypes.data for a in arrs])
+        c_numels = (C.c_int64 * n)(*[a.size for a in arrs])
+        self._ck(self.lib.cddpm_load_weights(self._h, c_names, c_ptrs, c_numels, n), "cddpm_load_weights")
+
+    def set_schedule(self, buffers: Mapping[str, object], objective: str = "pred_x0"):
+        """buffers: the GaussianDiffusion schedule buffers (host tensors/arrays of length T)."""
+        def host(name):
+            v = buffers[name]
+            if isinstance(v, torch.Tensor):
+                v = v.detach().to("cpu", torch.float32).numpy()
+            return np.ascontiguousarray(v, dtype=np.float32)
+        arrs = [host(k) for k in ("posterior_mean_coef1", "posterior_mean_coef2", "posterior_log_variance_clipped",
+                                  "sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod")]
+        self._qs = (host("sqrt_alphas_cumprod"), host("sqrt_one_minus_alphas_cumprod"))
+        T = arrs[0].shape[0]
+        self._ck(self.lib.cddpm_set_schedule(self._h, *[a.ctypes.data for a in arrs], T, OBJECTIVES[objective]),
+                 "cddpm_set_schedule")
+
+    def prepare_cond(self, cond: Optional[torch.Tensor], B: int):
+        if self.cond_dim > 0:
+            cond = _check_dev(cond, "cond", self.device)
+            if tuple(cond.shape) != (B, self.cond_dim):
+                raise RuntimeError(f"cond must be [{B}, {self.cond_dim}], got {tuple(cond.shape)}")
+            ptr = cond.data_ptr()
+        else:
+            ptr = None
+        self._ck(self.lib.cddpm_prepare_cond(self._h, ptr, B, _stream_ptr(self.device)), "cddpm_prepare_cond")
+        self._cond_keep = cond
+
+    # ------------------------------------------------------------------ the path
+    def unet_forward(self, x: torch.Tensor, t, cond: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """UNetModel.forward: x [B,1,H,W] fp32 on device, t int or int tensor [B]; cond [B,cond_dim] or None
+        to reuse the context of the previous prepare_cond."""
+        x = _check_dev(x, "x", self.device)
+        B, c, H, W = x.shape
+        if c != 1:
+            raise RuntimeError("x must be [B,1,H,W]")
+        if cond is not None or self.cond_dim == 0:
+            self.prepare_cond(cond, B)
+        out = torch.empty_like(x)
+        if isinstance(t, torch.Tensor):
+            tt = t.to(self.device, torch.int32).contiguous()
+            if tt.numel() != B:
+                raise RuntimeError("t must have B elements")
+            rc = self.lib.cddpm_unet_forward(self._h, x.data_ptr(), tt.data_ptr(), 0, out.data_ptr(), B, H, W,
+                                             _stream_ptr(self.device))
+        else:
+            rc = self.lib.cddpm_unet_forward(self._h, x.data_ptr(), None, int(t), out.data_ptr(), B, H, W,
+                                             _stream_ptr(self.device))
+        self._ck(rc, "cddpm_unet_forward")
+        return out
+
+    def reverse(self, x_T: torch.Tensor, cond: Optional[torch.Tensor], t_start: int, *, noise: Optional[torch.Tensor] = None,
+                seed: int = 0, slice0: int = 0) -> torch.Tensor:
+        """p_sample_loop from x_T: steps t_start-1 .. 0, returns the reconstruction in [0,1] (new tensor).
+        noise: [t_start, B, 1, H, W] with z_t at index t (index 0 unused), or None for the device Philox."""
+        x = _check_dev(x_T, "x_T", self.device).clone()
+        B, c, H, W = x.shape
+        if c != 1:
+            raise RuntimeError("x_T must be [B,1,H,W]")
+        self.prepare_cond(cond, B)
+        nptr = None
+        if noise is not None:
+            noise = _check_dev(noise, "noise", self.device)
+            if noise.numel() != t_start * B * H * W:
+                raise RuntimeError(f"noise must hold t_start*B*H*W = {t_start * B * H * W} values, got {noise.numel()}")
+            nptr = noise.data_ptr()
+        self._ck(self.lib.cddpm_reverse(self._h, x.data_ptr(), nptr, seed, slice0, t_start, B, H, W,
+                                        _stream_ptr(self.device)), "cddpm_reverse")
+        return x
+
+    def p_sample(self, x: torch.Tensor, t: int, cond: Optional[torch.Tensor] = None, *, z: Optional[torch.Tensor] = None,
+                 seed: int = 0, slice0: int = 0) -> torch.Tensor:
+        """one reverse step x_t -> x_{t-1} (values stay in [-1,1]); cond None reuses the prepared context."""
+        x = _check_dev(x, "x", self.device).clone()
+        B, _c, H, W = x.shape
+        if cond is not None or self.cond_dim == 0:
+            self.prepare_cond(cond, B)
+        zp = _check_dev(z, "z", self.device).data_ptr() if z is not None else None
+        self._ck(self.lib.cddpm_p_sample(self._h, x.data_ptr(), zp, seed, slice0, int(t), B, H, W,
+                                         _stream_ptr(self.device)), "cddpm_p_sample")
+        return x
+
+    def p_sample_(self, x: torch.Tensor, t: int, *, seed: int = 0, slice0: int = 0) -> torch.Tensor:
+        """in-place reverse step on a device tensor, context from the last prepare_cond (bench loop)"""
+        B, _c, H, W = x.shape
+        self._ck(self.lib.cddpm_p_sample(self._h, x.data_ptr(), None, seed, slice0, int(t), B, H, W,
+                                         _stream_ptr(self.device)), "cddpm_p_sample")
+        return x
+
+    PROF_CLASSES = ("conv3x3_mfma", "conv1x1_mfma", "attention", "groupnorm", "other")
+
+    def set_profiling(self, on: bool):
+        self._ck(self.lib.cddpm_set_profiling(self._h, int(on)), "cddpm_set_profiling")
+
+    def get_profile(self):
+        n = len(self.PROF_CLASSES)
+        ms, fl, by = (C.c_double * n)(), (C.c_double * n)(), (C.c_double * n)()
+        ln = (C.c_int64 * n)()
+        self._ck(self.lib.cddpm_get_profile(self._h, n, ms, fl, by, ln), "cddpm_get_profile")
+        return {name: dict(ms=ms[i], flops=fl[i], bytes=by[i], launches=int(ln[i])) for i, name in enumerate(self.PROF_CLASSES)}
+
+    def noise_fill(self, B: int, H: int, W: int, *, seed: int, stream_id: int, t: int = 0, slice0: int = 0) -> torch.Tensor:
+        out = torch.empty((B, 1, H, W), dtype=torch.float32, device=self.device)
+        self._ck(self.lib.cddpm_noise_fill(self._h, out.data_ptr(), seed, stream_id, t, slice0, B, H, W,
+                                           _stream_ptr(self.device)), "cddpm_noise_fill")
+        return out
+
+    def q_sample(self, x01: torch.Tensor, t, noise: torch.Tensor) -> torch.Tensor:
+        x01 = _check_dev(x01, "x01", self.device)
+        noise = _check_dev(noise, "noise", self.device)
+        B, _c, H, W = x01.shape
+        out = torch.empty_like(x01)
+        sa, s1 = self._qs
+        if isinstance(t, torch.Tensor):
+            tt = t.to(self.device, torch.int32).contiguous()
+            tp, tu = tt.data_ptr(), 0
+        else:
+            tt, tp, tu = None, None, int(t)
+        self._ck(self.lib.cddpm_q_sample(self._h, x01.data_ptr(), noise.data_ptr(), tp, tu, sa.ctypes.data, s1.ctypes.data,
+                                         sa.shape[0], out.data_ptr(), B, H, W, _stream_ptr(self.device)), "cddpm_q_sample")
+        torch.cuda.current_stream(self.device).synchronize()   # host tables were read asynchronously
+        return out
+
+    # ------------------------------------------------------------------ test surface
+    def block_names(self):
+        return [self.lib.cddpm_block_name(self._h, i).decode() for i in range(self.lib.cddpm_num_blocks(self._h))]
+
+    def forward_with_taps(self, x: torch.Tensor, t, cond) -> Dict[str, torch.Tensor]:
+        """forward that also returns every block output as NCHW tensors (tests only)."""
+        x = _check_dev(x, "x", self.device)
+        B, _c, H, W = x.shape
+        names = self.block_names()
+        bufs = {}
+        for i, n in enumerate(names):
+            if n == "out":
+                continue
+            cc, hh, ww = C.c_int(), C.c_int(), C.c_int()
+            self._ck(self.lib.cddpm_block_shape(self._h, i, H, W, C.byref(cc), C.byref(hh), C.byref(ww)), "cddpm_block_shape")
+            t_ = torch.empty((B, hh.value, ww.value, cc.value), dtype=torch.float32, device=self.device)
+            self._ck(self.lib.cddpm_set_tap(self._h, i, t_.data_ptr()), "cddpm_set_tap")
+            bufs[n] = t_
+        try:
+            out = self.unet_forward(x, t, cond)
+            torch.cuda.synchronize(self.device)
+        finally:
+            for i in range(len(names)):
+                self.lib.cddpm_set_tap(self._h, i, None)
+        res = {n: v.permute(0, 3, 1, 2).contiguous() for n, v in bufs.items()}
+        res["out"] = out
+        return res
+
+    def op_conv(self, src0, src1, coef, silu, upsample, weight, bias, res, res_upsample, ksize):
+        """fused conv on NHWC device tensors (see cddpm_op_conv); weight [Cout,Cin,k,k] host/any tensor."""
+        B, h, w, C0 = src0.shape
+        H, W = (2 * h, 2 * w) if upsample else (h, w)
+        C1 = src1.shape[-1] if src1 is not None else 0
+        wt = np.ascontiguousarray(weight.detach().cpu().numpy(), dtype=np.float32)
+        bs = np.ascontiguousarray(bias.detach().cpu().numpy(), dtype=np.float32)
+        Cout = wt.shape[0]
+        out = torch.empty((B, H, W, Cout), dtype=torch.float32, device=self.device)
+        self._ck(self.lib.cddpm_op_conv(
+            self._h, src0.data_ptr(), C0, src1.data_ptr() if src1 is not None else None, C1,
+            coef.data_ptr() if coef is not None else None, int(silu), int(upsample), wt.ctypes.data, bs.ctypes.data,
+            Cout, ksize, res.data_ptr() if res is not None else None, int(res_upsample), out.data_ptr(), B, H, W,
+            _stream_ptr(self.device)), "cddpm_op_conv")
+        return out
+
+    def op_gn_coef(self, src0, src1, gamma, beta, film):
+        B = src0.shape[0]
+        HW = src0.shape[1] * src0.shape[2]
+        C0 = src0.shape[-1]
+        C1 = src1.shape[-1] if src1 is not None else 0
+        g = np.ascontiguousarray(gamma.detach().cpu().numpy(), dtype=np.float32)
+        b = np.ascontiguousarray(beta.detach().cpu().numpy(), dtype=np.float32)
+        coef = torch.empty((3, B, C0 + C1), dtype=torch.float32, device=self.device)
+        self._ck(self.lib.cddpm_op_gn_coef(self._h, src0.data_ptr(), C0, src1.data_ptr() if src1 is not None else None, C1,
+                                           g.ctypes.data, b.ctypes.data, film.data_ptr() if film is not None else None,
+                                           coef.data_ptr(), B, HW, _stream_ptr(self.device)), "cddpm_op_gn_coef")
+        return coef
+
+    def op_attention(self, qkv):
+        B, N, C3 = qkv.shape
+        out = torch.empty((B, N, C3 // 3), dtype=torch.float32, device=self.device)
+        self._ck(self.lib.cddpm_op_attention(self._h, qkv.data_ptr(), out.data_ptr(), B, N, C3 // 3,
+                                             _stream_ptr(self.device)), "cddpm_op_attention")
+        return out

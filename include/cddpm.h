@@ -103,6 +103,11 @@ int cddpm_unet_forward(cddpm_handle h, const float* x_dev, const int32_t* t_dev,
 int cddpm_reverse(cddpm_handle h, float* img_inout_dev, const float* noise_dev, uint64_t seed,
                   uint64_t slice0, int t_start, int B, int H, int W, void* stream);
 
+/* Replaces one GaussianDiffusion.p_sample call (src/models/modules/cond_DDPM.py:432-444): img <- x_{t-1} from x_t,
+ * still in [-1,1]. z_dev: the step's N(0,1) draw [B,1,H,W], or NULL for the device Philox (ignored at t == 0). */
+int cddpm_p_sample(cddpm_handle h, float* img_inout_dev, const float* z_dev, uint64_t seed, uint64_t slice0,
+                   int t, int B, int H, int W, void* stream);
+
 /* Replaces torch.randn(shape) / torch.randn_like (src/models/modules/cond_DDPM.py:454, :440) with the
  * counter RNG: out_dev [B,1,H,W] ~ N(0,1); stream_id 0x1001 = x_T, 0x1002 = z_t. */
 int cddpm_noise_fill(cddpm_handle h, float* out_dev, uint64_t seed, uint32_t stream_id, int t,
@@ -114,6 +119,16 @@ int cddpm_noise_fill(cddpm_handle h, float* out_dev, uint64_t seed, uint32_t str
 int cddpm_q_sample(cddpm_handle h, const float* x01_dev, const float* noise_dev, const int32_t* t_dev, int t_uniform,
                    const float* sqrt_ac_host, const float* sqrt_1mac_host, int T,
                    float* out_dev, int B, int H, int W, void* stream);
+
+/* ---- measurement ------------------------------------------------------------------------------- */
+/* Per-kernel-class timing with HIP events recorded on the launch stream around every kernel (bench.py's
+ * roofline leg). Classes: 0 = fused 3x3 conv (MFMA), 1 = 1x1 conv (MFMA), 2 = attention core,
+ * 3 = GroupNorm statistics+coefficients, 4 = other (input conv, head, pooling). cddpm_get_profile
+ * synchronises, sums elapsed ms / algorithmic FLOPs / algorithmic bytes / launch counts per class since the
+ * last call, and clears the records. */
+#define CDDPM_PROF_CLASSES 5
+int cddpm_set_profiling(cddpm_handle h, int on);
+int cddpm_get_profile(cddpm_handle h, int ncls, double* ms, double* flops, double* bytes, int64_t* launches);
 
 /* ---- test / debug surface (used by tests/ only) ------------------------------------------------- */
 

@@ -89,8 +89,10 @@ def timestep_embedding(t: Tensor, dim: int, max_period: float = 10000.0) -> Tens
 # ----------------------------------------------------------------------------------------------
 
 def _gn(x: Tensor, sd, prefix: str) -> Tensor:
-    """GroupNorm32(32, C): fp32, eps 1e-5, affine (util.py:199-216)."""
-    return F.group_norm(x.float(), 32, sd[prefix + ".weight"], sd[prefix + ".bias"], eps=1e-5)
+    """GroupNorm32(32, C): fp32, eps 1e-5, affine (util.py:199-216). (Computes in the weights' dtype so the
+    same restatement run with float64 weights serves as the rounding-free yardstick in tests.)"""
+    w = sd[prefix + ".weight"]
+    return F.group_norm(x.to(w.dtype), 32, w, sd[prefix + ".bias"], eps=1e-5)
 
 
 def _conv(x: Tensor, sd, prefix: str, pad: int) -> Tensor:
@@ -130,14 +132,15 @@ def attention_block(x: Tensor, sd, prefix: str, head_channels: int = 64) -> Tens
     b, c, hh, ww = x.shape
     xf = x.reshape(b, c, -1)
     n = xf.shape[-1]
-    qkv = F.conv1d(F.group_norm(xf.float(), 32, sd[prefix + ".norm.weight"], sd[prefix + ".norm.bias"], eps=1e-5),
+    wn = sd[prefix + ".norm.weight"]
+    qkv = F.conv1d(F.group_norm(xf.to(wn.dtype), 32, wn, sd[prefix + ".norm.bias"], eps=1e-5),
                    sd[prefix + ".qkv.weight"], sd[prefix + ".qkv.bias"])
     heads = c // head_channels
     ch = head_channels
     q, k, v = qkv.chunk(3, dim=1)
     scale = 1 / math.sqrt(math.sqrt(ch))
     w = torch.einsum("bct,bcs->bts", (q * scale).reshape(b * heads, ch, n), (k * scale).reshape(b * heads, ch, n))
-    w = torch.softmax(w.float(), dim=-1)
+    w = torch.softmax(w.to(wn.dtype), dim=-1)
     a = torch.einsum("bts,bcs->bct", w, v.reshape(b * heads, ch, n)).reshape(b, -1, n)
     h = F.conv1d(a, sd[prefix + ".proj_out.weight"], sd[prefix + ".proj_out.bias"])
     return (xf + h).reshape(b, c, hh, ww)
@@ -146,7 +149,7 @@ def attention_block(x: Tensor, sd, prefix: str, head_channels: int = 64) -> Tens
 def unet_embedding(t: Tensor, cond: Optional[Tensor], sd, model_channels: int) -> Tensor:
     """emb = cat[time_embed(temb(t)), label_emb(cond)] (OpenAI_Unet.py:583-602, :846-852).
     The concat with label_emb(cond) is the 'Spark-encoder context concat' of the north star."""
-    te = timestep_embedding(t, model_channels)
+    te = timestep_embedding(t, model_channels).to(sd["time_embed.0.weight"].dtype)
     e = F.linear(te, sd["time_embed.0.weight"], sd["time_embed.0.bias"])
     e = F.linear(F.silu(e), sd["time_embed.2.weight"], sd["time_embed.2.bias"])
     if "label_emb.0.weight" in sd and cond is not None:
@@ -280,5 +283,11 @@ def p_losses_recon(x_start01: Tensor, t: Tensor, cond: Optional[Tensor], noise: 
     return loss.mean(), reco
 
 
-def to_torch_sd(sd_np: Dict[str, np.ndarray]) -> Dict[str, Tensor]:
-    return {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd_np.items()}
+def to_torch_sd(sd_np: Dict[str, np.ndarray], dtype=torch.float32) -> Dict[str, Tensor]:
+    return {k: torch.from_numpy(np.ascontiguousarray(v)).to(dtype) for k, v in sd_np.items()}
+
+
+def to_float64(d: Dict[str, Tensor]) -> Dict[str, Tensor]:
+    """float64 copies of a state_dict / buffer dict: the same restatement then runs without fp32 rounding
+    (yardstick for how far two fp32 implementations may legitimately differ)."""
+    return {k: v.double() for k, v in d.items()}

@@ -1,0 +1,142 @@
+"""GPU parity of the whole path through the C ABI: UNet forward (per block, vs the oracle run on the same
+host), the committed reference golden vectors, and the reverse loops (config 1 and friends).
+North-star tolerance: |delta| <= 1e-4 per pixel on the reconstruction; UNet outputs are O(1), same bound."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden, load_pkg
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def eng1000(engine_factory):
+    return engine_factory(timesteps=1000, max_batch=4, max_h=128, max_w=128)
+
+
+@pytest.fixture(scope="module")
+def eng50(engine_factory):
+    return engine_factory(timesteps=50, max_batch=4, max_h=128, max_w=128)
+
+
+def inputs(synth, B, H, W, slice0=0):
+    x = torch.from_numpy(synth.noise_xT(2, slice0, B, H, W))
+    cond = torch.from_numpy(synth.synth_cond(1, slice0, B))
+    return x, cond
+
+
+def test_unet_blocks_vs_oracle(eng1000, synth, oracle, sd_torch):
+    B, H, W = 2, 32, 32
+    x, cond = inputs(synth, B, H, W)
+    taps = {}
+    with torch.no_grad():
+        ref = oracle.unet_forward(x, torch.full((B,), 500), cond, sd_torch, taps=taps)
+    got = eng1000.forward_with_taps(x.cuda(), 500, cond.cuda())
+    report, worst = [], 0.0
+    for name in eng1000.block_names():
+        r = ref if name == "out" else taps[name]
+        g = got[name].cpu()
+        assert g.shape == r.shape, (name, g.shape, r.shape)
+        err = float((g - r).abs().max())
+        rel = err / (1e-6 + float(r.abs().max()))
+        report.append(f"{name:18s} max|d|={err:.3e} rel={rel:.3e}")
+        worst = max(worst, rel)
+    print("\n".join(report))
+    assert worst < 2e-5, "\n".join(report)
+    assert float((got["out"].cpu() - ref).abs().max()) < TOL
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 32, 32), (1, 64, 96), (1, 96, 96), (1, 128, 128)])
+def test_unet_forward_golden(eng1000, synth, B, H, W):
+    g = golden(f"unet_fwd_B{B}_{H}x{W}")
+    x, cond = inputs(synth, B, H, W)
+    xd, cd = x.cuda(), cond.cuda()
+    for key in g.files:
+        if key == "tmixed":
+            t = torch.tensor([123, 877][:B], dtype=torch.int32)
+        else:
+            t = int(key[1:])
+        out = eng1000.unet_forward(xd, t, cd).cpu().numpy()
+        err = np.abs(out - g[key]).max()
+        assert err < TOL, (key, err)
+
+
+LOOPS = [("loop_B2_32x32_T1000_start8", 1000, 8, 2, 32, 32, 0),
+         ("loop_B2_32x32_T50_start0", 50, 0, 2, 32, 32, 0),
+         ("loop_B3_32x48_T1000_start5_slice7", 1000, 5, 3, 32, 48, 7),
+         ("loop_cfg1_B4_128x128_T50_start0", 50, 0, 4, 128, 128, 0),
+         ("loop_B1_128x128_T1000_start50", 1000, 50, 1, 128, 128, 0)]
+
+
+@pytest.mark.parametrize("name,T,start_t,B,H,W,slice0", LOOPS, ids=[l[0] for l in LOOPS])
+def test_reverse_loop_golden(eng1000, eng50, synth, name, T, start_t, B, H, W, slice0):
+    """p_sample_loop vs the reference's own output (tests/golden), explicit z_t injected."""
+    eng = eng1000 if T == 1000 else eng50
+    steps = T if start_t == 0 else start_t
+    x, cond = inputs(synth, B, H, W, slice0)
+    noise = np.zeros((steps, B, 1, H, W), np.float32)
+    for t in range(1, steps):
+        noise[t] = synth.noise_z(3, t, slice0, B, H, W)
+    out = eng.reverse(x.cuda(), cond.cuda(), steps, noise=torch.from_numpy(noise).cuda()).cpu().numpy()
+    ref = golden(name)["out"]
+    err = np.abs(out - ref).max()
+    print(name, "max|delta| vs reference golden:", err)
+    assert out.min() >= 0.0 and out.max() <= 1.0
+    assert err < TOL, err
+    # same loop with the device Philox instead of uploaded noise: integer stream identical, floats within ulps
+    out2 = eng.reverse(x.cuda(), cond.cuda(), steps, noise=None, seed=3, slice0=slice0).cpu().numpy()
+    err2 = np.abs(out2 - ref).max()
+    print(name, "device-RNG max|delta|:", err2)
+    assert err2 < TOL, err2
+
+
+def test_rounding_yardstick_fp64(eng50, synth, oracle, sd_torch):
+    """How far may two correct fp32 implementations differ? Run the oracle in float64 (no fp32 rounding) and
+    compare both the reference's fp32 output (golden) and the HIP output with it on the 50-step loop."""
+    B, H, W, T = 2, 32, 32, 50
+    x, cond = inputs(synth, B, H, W)
+    zs = {t: torch.from_numpy(synth.noise_z(3, t, 0, B, H, W)) for t in range(1, T)}
+    sd64, buf64 = oracle.to_float64(sd_torch), oracle.to_float64(oracle.schedule_buffers(T))
+    truth = oracle.p_sample_loop(x.double(), cond.double(), sd64, buf64, lambda t: zs[t].double(), start_t=0).numpy()
+    noise = torch.zeros(T, B, 1, H, W)
+    for t, z in zs.items():
+        noise[t] = z
+    hip = eng50.reverse(x.cuda(), cond.cuda(), T, noise=noise.cuda()).cpu().numpy()
+    ref = golden("loop_B2_32x32_T50_start0")["out"]
+    e_ref, e_hip, e_pair = np.abs(ref - truth).max(), np.abs(hip - truth).max(), np.abs(hip - ref).max()
+    print(f"fp64 yardstick (T=50, 32x32): reference-fp32 vs fp64 {e_ref:.3e}; HIP vs fp64 {e_hip:.3e}; HIP vs reference {e_pair:.3e}")
+    assert e_hip < TOL
+    assert e_hip < 4 * e_ref + 1e-6, "HIP rounding noise should be of the order of the reference's own"
+
+
+def test_p_sample_single_step(eng1000, synth, oracle, sd_torch):
+    B, H, W = 2, 32, 32
+    x, cond = inputs(synth, B, H, W)
+    z = torch.from_numpy(synth.noise_z(3, 700, 0, B, H, W))
+    buf = oracle.schedule_buffers(1000)
+    with torch.no_grad():
+        ref = oracle.p_sample(x, 700, cond, sd_torch, buf, z)
+    got = eng1000.p_sample(x.cuda(), 700, cond.cuda(), z=z.cuda()).cpu()
+    assert float((got - ref).abs().max()) < TOL
+
+
+def test_sharding_invariance(eng1000, synth):
+    """a slice's result depends only on its global index: batch [0..3] == batches [0,1] + [2,3] bit for bit"""
+    H = W = 32
+    x, cond = inputs(synth, 4, H, W)
+    full = eng1000.reverse(x.cuda(), cond.cuda(), 6, seed=11, slice0=0)
+    lo = eng1000.reverse(x[:2].cuda(), cond[:2].cuda(), 6, seed=11, slice0=0)
+    hi = eng1000.reverse(x[2:].cuda(), cond[2:].cuda(), 6, seed=11, slice0=2)
+    assert torch.equal(full[:2], lo) and torch.equal(full[2:], hi)
+
+
+def test_errors_are_loud(eng1000, synth):
+    x, cond = inputs(synth, 2, 32, 32)
+    with pytest.raises(RuntimeError):
+        eng1000.unet_forward(x, 3, cond)            # CPU tensors: no fallback
+    with pytest.raises(RuntimeError):
+        eng1000.unet_forward(x.cuda()[:, :, :30], 3, cond.cuda())   # H not a multiple of 4
+    with pytest.raises(RuntimeError):
+        eng1000.unet_forward(x.cuda(), 1000, cond.cuda())           # t out of range
