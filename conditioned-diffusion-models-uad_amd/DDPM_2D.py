@@ -1,0 +1,136 @@
+"""Host-side mirror of the reference LightningModule `DDPM_2D` (reference src/models/DDPM_2D.py:17-308):
+the Hydra target `src.models.DDPM_2D.DDPM_2D` of `experiment=cDDPM/DDPM_cond_spark_2D`.
+
+Kept: constructor `DDPM_2D(cfg, prefix=None)` reading the same cfg keys with the same defaults (:37-77),
+attributes `.encoder`, `.diffusion`, `.test_timesteps`, `forward(x) -> c`, the state_dict prefixes
+`encoder.*` / `diffusion.model.*` / `diffusion.<buffers>`, `configure_optimizers`.
+Added, behind a cfg switch that is absent (= reference behaviour) by default:
+    cfg.reverse_sampling: true   ->  test-time reconstruction = the iterative reverse loop
+                                     (GaussianDiffusion.p_sample_loop) instead of the single-step x0 estimate
+    cfg.reverse_start_t: int     ->  start_t of that loop (0 = all `timesteps` steps)
+
+Out of scope here ('next' rows): the timm ResNet-50 context encoder (f2) -- built through
+timm when it is importable, otherwise an `encoder=` module must be supplied; simplex noise (f3); training and the
+scipy post-processing of utils_eval (f4). pytorch_lightning / omegaconf are used when installed and replaced by
+nn.Module / a plain attribute dict when not.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from .OpenAI_Unet import UNetModel as OpenAI_UNet
+from .cond_DDPM import GaussianDiffusion
+
+try:  # Lightning 1.5 path first (what the reference pins), then 2.x, then a plain Module
+    from pytorch_lightning.core.lightning import LightningModule as _Base  # type: ignore
+except Exception:  # pragma: no cover - depends on the environment
+    try:
+        from pytorch_lightning import LightningModule as _Base  # type: ignore
+    except Exception:
+        _Base = nn.Module
+
+
+class AttrDict(dict):
+    """cfg stand-in when omegaconf is absent: cfg.key, cfg['key'], cfg.get(key, default)"""
+    __getattr__ = dict.get
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+
+def _cfg_get(cfg, key, default=None):
+    try:
+        v = cfg.get(key, default)
+    except AttributeError:
+        v = getattr(cfg, key, default)
+    return default if v is None else v
+
+
+def build_encoder(cfg):
+    """get_encoder (reference src/models/modules/DDPM_encoder.py:6-29): timm resnet50, in_chans=1,
+    num_classes=cond_dim. Parity of this module is unpinned offline (timm 0.6.7 is not in the image)."""
+    try:
+        import timm  # type: ignore
+    except Exception as e:
+        raise ImportError("the Spark context encoder needs timm (resnet50, in_chans=1, num_classes=cond_dim); "
+                          "timm is not importable here -- pass DDPM_2D(cfg, encoder=<module>) instead") from e
+    dim = int(_cfg_get(cfg, "cond_dim", 128))
+    enc = timm.create_model(_cfg_get(cfg, "version", "resnet50"), pretrained=False, in_chans=1, num_classes=dim)
+    return enc, dim
+
+
+class DDPM_2D(_Base):
+    def __init__(self, cfg, prefix=None, encoder=None):
+        super().__init__()
+        if isinstance(cfg, dict) and not isinstance(cfg, AttrDict):
+            cfg = AttrDict(cfg)
+        self.cfg = cfg
+        if _cfg_get(cfg, "condition", True):
+            cfg["cond_dim"] = _cfg_get(cfg, "unet_dim", 128)
+            if encoder is not None:
+                self.encoder, out_features = encoder, int(cfg["cond_dim"])
+            else:
+                self.encoder, out_features = build_encoder(cfg)
+        else:
+            out_features = None
+        size = (int(cfg["imageDim"][0] / cfg["rescaleFactor"]), int(cfg["imageDim"][1] / cfg["rescaleFactor"]))
+        model = OpenAI_UNet(
+            image_size=size, in_channels=1, model_channels=_cfg_get(cfg, "unet_dim", 64), out_channels=1,
+            num_res_blocks=_cfg_get(cfg, "num_res_blocks", 3), attention_resolutions=tuple(_cfg_get(cfg, "att_res", [3, 6, 12])),
+            dropout=_cfg_get(cfg, "dropout_unet", 0), channel_mult=_cfg_get(cfg, "dim_mults", [1, 2, 4, 8]),
+            conv_resample=True, dims=2, num_classes=out_features, use_checkpoint=False, use_fp16=True, num_heads=1,
+            num_head_channels=64, num_heads_upsample=-1, use_scale_shift_norm=True, resblock_updown=True,
+            use_new_attention_order=True, use_spatial_transformer=_cfg_get(cfg, "spatial_transformer", False),
+            transformer_depth=1)
+        model.convert_to_fp16()
+        timesteps = _cfg_get(cfg, "timesteps", 1000)
+        self.test_timesteps = _cfg_get(cfg, "test_timesteps", 150)
+        self.diffusion = GaussianDiffusion(
+            model, image_size=size, timesteps=timesteps, sampling_timesteps=_cfg_get(cfg, "sampling_timesteps", timesteps),
+            objective=_cfg_get(cfg, "objective", "pred_x0"), channels=1, loss_type=_cfg_get(cfg, "loss", "l1"),
+            p2_loss_weight_gamma=_cfg_get(cfg, "p2_gamma", 0), cfg=cfg)
+        self.prefix = prefix
+        if hasattr(self, "save_hyperparameters") and _Base is not nn.Module:
+            try:
+                self.save_hyperparameters()
+            except Exception:
+                pass
+
+    def forward(self, x):
+        """encode slices [D,1,H,W] -> context c [D, cond_dim] (reference :102-111)"""
+        if _cfg_get(self.cfg, "condition", True):
+            return self.encoder(x)
+        return None
+
+    @torch.no_grad()
+    def reconstruct(self, input, features=None, noise=None, t=None):
+        """The reconstruction call of test_step (reference :225-247), [D,1,H,W] in [0,1] -> (loss, reco).
+        reverse_sampling off: `self.diffusion(input, cond=features, t=t-1, noise=noise)` (single step);
+        reverse_sampling on : the reverse loop from pure noise / from start_t (p_sample_loop)."""
+        if features is None:
+            features = self(input)
+        with torch.autocast("cuda", enabled=False):          # the path is fp32 whatever the Trainer's precision
+            if _cfg_get(self.cfg, "reverse_sampling", False):
+                start_t = int(_cfg_get(self.cfg, "reverse_start_t", 0))
+                reco = self.diffusion.p_sample_loop(tuple(input.shape), cond=features, start_t=start_t)
+                loss = (reco - input).abs().mean()
+                return loss, reco
+            t = self.test_timesteps if t is None else t
+            return self.diffusion(input, cond=features, t=t - 1, noise=noise)
+
+    def test_step(self, batch, batch_idx: int):
+        """vol [1,1,H,W,D] -> slices [D,1,H,W] -> reconstruction [H,W,D] (reference :171-286). The scipy/sklearn
+        post-processing `_test_step` of the reference is called when `src.utils.utils_eval` is importable
+        (i.e. when this class is dropped into the reference tree); otherwise the tensors are returned."""
+        vol = batch["vol"]
+        data = vol["data"] if isinstance(vol, dict) else vol
+        input = data.squeeze(0).permute(3, 0, 1, 2)                      # [D,1,H,W]   (:210)
+        features = self(input)
+        noise = torch.randn_like(input)                                  # Gaussian branch of gen_noise
+        loss, reco = self.reconstruct(input, features, noise)
+        final_volume = reco.clone().squeeze().permute(1, 2, 0).unsqueeze(0).unsqueeze(0)   # (:256-262)
+        return {"loss": loss, "final_volume": final_volume, "input": input, "features": features}
+
+    def configure_optimizers(self):
+        return torch.optim.Adam(self.parameters(), lr=_cfg_get(self.cfg, "lr", 1e-4))

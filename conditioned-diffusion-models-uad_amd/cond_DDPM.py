@@ -1,0 +1,213 @@
+"""Host-side mirror of the reference diffusion wrapper, `GaussianDiffusion`
+(reference src/models/modules/cond_DDPM.py:289-655), running on the HIP engine.
+
+Same constructor arguments, the same 13 registered schedule buffers (they are part of checkpoints), the same
+method names and argument meaning for the path in scope:
+
+    p_sample_loop(shape, cond, cond_scale, box, start_t, noise, x_start)   :446-464  -> cddpm_reverse
+    p_sample(x, t, clip_denoised, cond, cond_scale, noise)                 :432-444  -> cddpm_p_sample
+    sample(batch_size, cond, ...)                                          :517-530
+    q_sample(x_start, t, noise)                                            :548-554  -> cddpm_q_sample
+    forward(img, t, cond=, noise=) -> (loss, reco)   (single-step reconstruction, :565-655)
+    model_predictions / p_mean_variance / q_posterior                      :391-430
+
+Differences, on purpose:
+  * no CPU path: tensors must live on the MI355X, otherwise a RuntimeError (never a silent fallback);
+  * `use_spatial_transformer` is set to False here -- the reference reads it in model_predictions (:401) but
+    never assigns it, so its own p_sample crashes; this is the intended semantics (experiment yaml :31);
+  * Gaussian branch only: the simplex branch (`noise is not None`: gen_noise redrawn every step on the CPU,
+    :441-443, :450-452) and `box` in-painting are outside the accelerated path and raise NotImplementedError;
+  * noise: x_T and z_t come from the counter RNG (synth.py / on-device Philox) seeded from torch's global
+    generator, so `torch.manual_seed` still makes runs reproducible; pass `seed=`/`slice0=` to pin them.
+"""
+from __future__ import annotations
+
+from collections import namedtuple
+
+import torch
+import torch.nn as nn
+
+from . import schedule as _schedule
+from . import synth as _synth
+
+ModelPrediction = namedtuple("ModelPrediction", ["pred_noise", "pred_x_start"])
+
+
+def normalize_to_neg_one_to_one(img):
+    return img * 2 - 1
+
+
+def unnormalize_to_zero_to_one(t):
+    return (t + 1) * 0.5
+
+
+def _extract(a, t, x_shape):
+    return a.gather(-1, t).reshape(t.shape[0], *((1,) * (len(x_shape) - 1)))
+
+
+class GaussianDiffusion(nn.Module):
+    def __init__(self, model, *, image_size, channels=3, timesteps=1000, sampling_timesteps=None, loss_type="l1",
+                 objective="pred_noise", beta_schedule="cosine", p2_loss_weight_gamma=0., p2_loss_weight_k=1,
+                 ddim_sampling_eta=1., inpaint=False, cfg=None):
+        super().__init__()
+        assert objective in {"pred_noise", "pred_x0"}, \
+            "objective must be either pred_noise (predict noise) or pred_x0 (predict image start)"
+        self.cfg = cfg
+        self.channels = channels
+        self.image_size = image_size
+        self.model = model
+        self.objective = objective
+        self.inpaint = inpaint
+        self.loss_type = loss_type
+        self.use_spatial_transformer = False
+        bufs = _schedule.schedule_buffers(timesteps, beta_schedule, p2_loss_weight_gamma, p2_loss_weight_k)
+        self.num_timesteps = int(bufs["betas"].shape[0])
+        self.sampling_timesteps = timesteps if sampling_timesteps is None else sampling_timesteps
+        assert self.sampling_timesteps <= timesteps
+        self.is_ddim_sampling = self.sampling_timesteps < timesteps
+        self.ddim_sampling_eta = ddim_sampling_eta
+        for name in _schedule.BUFFER_NAMES:
+            self.register_buffer(name, bufs[name])
+        self._sched_token = None
+
+    # ---- engine plumbing --------------------------------------------------------------------------
+    def _engine(self, B, H, W, device):
+        """the UNet's packed HIP engine with THIS module's schedule installed"""
+        token = tuple((getattr(self, n).data_ptr(), getattr(self, n)._version) for n in ("betas", "posterior_mean_coef1"))
+        if token != self._sched_token:
+            self.model._hip.set_schedule({n: getattr(self, n) for n in _schedule.BUFFER_NAMES}, self.objective)
+            self._sched_token = token
+        return self.model.hip_engine(B, H, W, device)
+
+    @staticmethod
+    def _draw_seed(seed):
+        if seed is not None:
+            return int(seed)
+        return int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())   # follows torch.manual_seed
+
+    @property
+    def loss_fn(self):
+        if self.loss_type == "l1":
+            return torch.nn.functional.l1_loss
+        if self.loss_type == "l2":
+            return torch.nn.functional.mse_loss
+        raise ValueError(f"invalid loss type {self.loss_type}")
+
+    # ---- posterior helpers (elementwise; kept for API completeness) -----------------------------------
+    def predict_start_from_noise(self, x_t, t, noise):
+        return (_extract(self.sqrt_recip_alphas_cumprod, t, x_t.shape) * x_t
+                - _extract(self.sqrt_recipm1_alphas_cumprod, t, x_t.shape) * noise)
+
+    def predict_noise_from_start(self, x_t, t, x0):
+        return ((_extract(self.sqrt_recip_alphas_cumprod, t, x_t.shape) * x_t - x0)
+                / _extract(self.sqrt_recipm1_alphas_cumprod, t, x_t.shape))
+
+    def q_posterior(self, x_start, x_t, t):
+        mean = (_extract(self.posterior_mean_coef1, t, x_t.shape) * x_start
+                + _extract(self.posterior_mean_coef2, t, x_t.shape) * x_t)
+        return (mean, _extract(self.posterior_variance, t, x_t.shape),
+                _extract(self.posterior_log_variance_clipped, t, x_t.shape))
+
+    @torch.no_grad()
+    def model_predictions(self, x, t, cond, cond_scale, clip_x_start=False):
+        eng = self._engine(x.shape[0], x.shape[2], x.shape[3], x.device)
+        out = eng.unet_forward(x, t, cond)
+        clip = (lambda v: v.clamp(-1., 1.)) if clip_x_start else (lambda v: v)
+        if self.objective == "pred_noise":
+            return ModelPrediction(out, clip(self.predict_start_from_noise(x, t, out)))
+        return ModelPrediction(self.predict_noise_from_start(x, t, out), clip(out))
+
+    @torch.no_grad()
+    def p_mean_variance(self, x, t, clip_denoised: bool, cond=None, cond_scale=1.):
+        x_start = self.model_predictions(x, t, cond, cond_scale, clip_denoised).pred_x_start
+        return self.q_posterior(x_start=x_start, x_t=x, t=t)
+
+    # ---- the hot path -----------------------------------------------------------------------------------
+    @torch.no_grad()
+    def p_sample(self, x, t: int, clip_denoised=True, cond=None, cond_scale=1., noise=None, *, z=None, seed=None, slice0=0):
+        """x_t -> x_{t-1} (cond_DDPM.py:432-444). `z`: this step's N(0,1) draw (else drawn on the device)."""
+        if noise is not None:
+            raise NotImplementedError("simplex-noise branch (gen_noise each step, cond_DDPM.py:441-443) is not accelerated")
+        if not clip_denoised:
+            raise NotImplementedError("clip_denoised=False is not part of the reconstruction path")
+        B, _c, H, W = x.shape
+        eng = self._engine(B, H, W, x.device)
+        return eng.p_sample(x.float(), int(t), cond.float() if cond is not None else None, z=z, seed=self._draw_seed(seed), slice0=slice0)
+
+    @torch.no_grad()
+    def p_sample_loop(self, shape, cond=None, cond_scale=1., box=None, start_t=0, noise=None, x_start=None, *,
+                      x_T=None, z_noise=None, seed=None, slice0=0, device=None):
+        """Full reverse loop (cond_DDPM.py:446-464): T = num_timesteps if start_t == 0 else start_t, x_T ~ N(0,1),
+        T steps, result mapped to [0,1]. Extras: x_T / z_noise ([T,B,1,H,W], z_t at index t) inject given draws,
+        seed / slice0 key the counter RNG (slice0 = global index of the first slice, for sharded runs)."""
+        if noise is not None:
+            raise NotImplementedError("simplex-noise branch (q_sample start + gen_noise per step, cond_DDPM.py:450-452) "
+                                      "is not accelerated; call with noise=None")
+        if box is not None:
+            raise NotImplementedError("box in-painting is not part of the cDDPM reconstruction path")
+        B, _c, H, W = shape
+        dev = torch.device(device) if device is not None else (cond.device if cond is not None else self.betas.device)
+        T = self.num_timesteps if start_t == 0 else int(start_t)
+        eng = self._engine(B, H, W, dev)
+        seed = self._draw_seed(seed)
+        if x_T is None:
+            x_T = eng.noise_fill(B, H, W, seed=seed, stream_id=_synth.STREAM_XT, slice0=slice0)
+        return eng.reverse(x_T, cond.float() if cond is not None else None, T, noise=z_noise, seed=seed, slice0=slice0)
+
+    @torch.no_grad()
+    def ddim_sample(self, *a, **k):
+        raise NotImplementedError("DDIM sampling (cond_DDPM.py:466-515) is outside the accelerated path "
+                                  "(sampling_timesteps == timesteps in the cDDPM experiment)")
+
+    @torch.no_grad()
+    def sample(self, batch_size=16, cond=None, cond_scale=1., box=None, x_start=None, start_t=0, noise=None, **kw):
+        """(cond_DDPM.py:517-530) image_size may be an int or an (H, W) pair, as DDPM_2D passes it."""
+        hw = self.image_size if isinstance(self.image_size, (tuple, list)) else (self.image_size, self.image_size)
+        if self.is_ddim_sampling:
+            return self.ddim_sample()
+        return self.p_sample_loop((batch_size, self.channels, int(hw[0]), int(hw[1])), cond=cond, cond_scale=cond_scale,
+                                  box=box, start_t=start_t, noise=noise, x_start=x_start, **kw)
+
+    @torch.no_grad()
+    def q_sample(self, x_start, t, noise=None):
+        """sqrt(abar_t) x0 + sqrt(1 - abar_t) eps on x0 in [-1,1] (cond_DDPM.py:548-554)."""
+        if noise is None:
+            noise = torch.randn_like(x_start)
+        B, _c, H, W = x_start.shape
+        eng = self._engine(B, H, W, x_start.device)
+        # the kernel fuses the [0,1] -> [-1,1] map; feed it the inverse so callers keep the reference's convention
+        return eng.q_sample((x_start.float() + 1) * 0.5, t, noise.float())
+
+    @torch.no_grad()
+    def p_losses(self, x_start, t, cond=None, noise=None, box=None, scale_patch=1, onlybox=False, mask=None):
+        """single-step reconstruction (cond_DDPM.py:565-645), x_start in [-1,1]; returns (loss, reco in [0,1])"""
+        if box is not None or self.inpaint:
+            raise NotImplementedError("box / inpaint variants are not part of the cDDPM path")
+        if noise is None:
+            noise = torch.randn_like(x_start)
+        B, _c, H, W = x_start.shape
+        eng = self._engine(B, H, W, x_start.device)
+        x = eng.q_sample((x_start.float() + 1) * 0.5, t, noise.float())
+        out = eng.unet_forward(x, t, cond.float() if cond is not None else None)
+        if self.objective == "pred_noise":
+            target = noise
+        else:
+            if mask is not None:
+                out = out * mask
+            target = x_start
+        loss = self.loss_fn(out, target, reduction="none").reshape(B, -1).mean(dim=1)
+        loss = loss * self.p2_loss_weight.gather(-1, t.long())
+        if self.objective == "pred_noise":
+            reco = x - _extract(self.sqrt_one_minus_alphas_cumprod, t.long(), x.shape) * out
+        else:
+            reco = out
+        return loss.mean(), unnormalize_to_zero_to_one(reco)
+
+    def forward(self, img, t=None, *args, **kwargs):
+        """(cond_DDPM.py:647-655) img in [0,1]; t: scalar timestep for the whole batch or None for random."""
+        b = img.shape[0]
+        if t is None:
+            t = torch.randint(0, self.num_timesteps, (b,), device=img.device).long()
+        else:
+            t = (torch.ones([b], device=img.device) * t).long()
+        return self.p_losses(normalize_to_neg_one_to_one(img), t, *args, **kwargs)

@@ -1,0 +1,156 @@
+"""CPU: host-side logic of the package -- counter RNG, synthetic weights, schedule, the class mirrors'
+surfaces, the C ABI library (loads, exports every declared symbol, fails loudly without a GPU)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, golden, load_pkg
+
+
+def test_philox_known_answers(synth):
+    """Random123 known-answer vectors for Philox4x32-10"""
+    def run(c, k):
+        return [int(v) for v in synth.philox4x32(np.uint32(c[0]), np.uint32(c[1]), np.uint32(c[2]), np.uint32(c[3]), k[0], k[1])]
+    assert run((0, 0, 0, 0), (0, 0)) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    f = 0xffffffff
+    assert run((f, f, f, f), (f, f)) == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    assert run((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0)) == \
+        [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+
+
+def test_noise_is_keyed_by_global_slice(synth):
+    a = synth.noise_z(3, 17, 0, 4, 8, 8)
+    b = synth.noise_z(3, 17, 2, 2, 8, 8)
+    np.testing.assert_array_equal(a[2:], b)                      # shard [2,4) regenerates its own draws
+    assert not np.array_equal(synth.noise_z(3, 18, 0, 1, 8, 8), a[:1])
+    z = synth.noise_xT(5, 0, 8, 64, 64)
+    assert abs(z.mean()) < 0.02 and abs(z.std() - 1) < 0.02 and np.isfinite(z).all()
+    u = synth.synth_slices(1, 0, 2, 16, 16)
+    assert u.min() > 0 and u.max() < 1
+
+
+def test_synthetic_state_dict_matches_reference_inventory(sd_np, synth):
+    assert len(sd_np) == 316 and sum(v.size for v in sd_np.values()) == 43871873
+    assert sd_np["middle_block.1.qkv.weight"].shape == (768, 256, 1)
+    assert sd_np["output_blocks.7.1.in_layers.2.weight"].shape == (256, 256, 3, 3)      # the up ResBlock
+    assert sd_np["output_blocks.8.0.skip_connection.weight"].shape == (128, 384, 1, 1)
+    assert sd_np["input_blocks.1.0.emb_layers.1.weight"].shape == (256, 1024)
+    assert all(np.abs(v).max() > 0 for v in sd_np.values())       # nothing zero-initialised
+
+
+def test_package_schedule_equals_oracle(oracle):
+    sched = load_pkg("schedule")
+    for T, kind in ((1000, "cosine"), (50, "cosine"), (200, "linear")):
+        a, b = sched.schedule_buffers(T, kind), oracle.schedule_buffers(T, kind)
+        assert list(a.keys()) == list(sched.BUFFER_NAMES)
+        for k in a:
+            assert torch.equal(a[k], b[k]), k
+    with pytest.raises(ValueError):
+        sched.schedule_buffers(10, "quadratic")
+
+
+def test_unet_mirror_state_dict_and_surface(sd_np, synth):
+    U = load_pkg("OpenAI_Unet")
+    m = U.UNetModel(image_size=(128, 128), in_channels=1, model_channels=128, out_channels=1, num_res_blocks=3,
+                    attention_resolutions=(3, 6, 12), dropout=0, channel_mult=[1, 2, 2], conv_resample=True, dims=2,
+                    num_classes=128, use_checkpoint=False, use_fp16=True, num_heads=1, num_head_channels=64,
+                    num_heads_upsample=-1, use_scale_shift_norm=True, resblock_updown=True, use_new_attention_order=True,
+                    use_spatial_transformer=False, transformer_depth=1)
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(sd_np.keys())                  # same names, same registration order
+    assert all(tuple(sd[k].shape) == sd_np[k].shape for k in sd)
+    # zero-initialised modules as in the reference (zero_module): out.2, out_layers.3, proj_out
+    assert float(sd["out.2.weight"].abs().max()) == 0 and float(sd["middle_block.1.proj_out.weight"].abs().max()) == 0
+    assert float(sd["input_blocks.1.0.out_layers.3.weight"].abs().max()) == 0
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()}, strict=True)
+    m.convert_to_fp16()
+    assert all(p.dtype == torch.float32 for p in m.parameters())   # no-op, as in the reference
+    with pytest.raises(RuntimeError, match="no CPU fallback|MI355X"):
+        m(torch.zeros(1, 1, 32, 32), torch.zeros(1, dtype=torch.long), cond=torch.zeros(1, 128))
+    with pytest.raises(NotImplementedError):
+        U.UNetModel(image_size=32, in_channels=1, model_channels=128, out_channels=1, num_res_blocks=3,
+                    attention_resolutions=(), use_scale_shift_norm=False, resblock_updown=True,
+                    use_new_attention_order=True, num_head_channels=64)
+
+
+def test_diffusion_mirror_buffers_and_errors(oracle):
+    U, D = load_pkg("OpenAI_Unet"), load_pkg("cond_DDPM")
+    m = U.UNetModel(image_size=(32, 32), in_channels=1, model_channels=128, out_channels=1, num_res_blocks=3,
+                    attention_resolutions=(3, 6, 12), channel_mult=[1, 2, 2], num_classes=128, num_head_channels=64,
+                    use_scale_shift_norm=True, resblock_updown=True, use_new_attention_order=True)
+    d = D.GaussianDiffusion(m, image_size=(32, 32), timesteps=1000, sampling_timesteps=1000, objective="pred_x0",
+                            channels=1, loss_type="l1", p2_loss_weight_gamma=0, cfg=None)
+    g = golden("schedule_T1000")
+    names = [n for n, _ in d.named_buffers()]
+    assert names == list(g.files) or set(names) == set(g.files)
+    for n in g.files:
+        np.testing.assert_array_equal(getattr(d, n).numpy(), g[n], err_msg=n)
+    assert d.num_timesteps == 1000 and not d.is_ddim_sampling and d.use_spatial_transformer is False
+    keys = d.state_dict().keys()
+    assert "model.input_blocks.0.0.weight" in keys and "betas" in keys          # -> diffusion.model.* in DDPM_2D
+    with pytest.raises(RuntimeError):
+        d.p_sample_loop((1, 1, 32, 32), cond=torch.zeros(1, 128))                # CPU tensors: loud, no fallback
+    with pytest.raises(NotImplementedError):
+        d.p_sample_loop((1, 1, 32, 32), cond=torch.zeros(1, 128), noise=torch.zeros(1))   # simplex branch
+    with pytest.raises(AssertionError):
+        D.GaussianDiffusion(m, image_size=32, objective="pred_v")
+    with pytest.raises(ValueError):
+        D.GaussianDiffusion(m, image_size=32, beta_schedule="sigmoid", objective="pred_x0")
+
+
+def test_ddpm2d_mirror_builds_from_experiment_cfg():
+    M = load_pkg("DDPM_2D")
+    cfg = dict(imageDim=[192, 192, 100], rescaleFactor=2, unet_dim=128, dim_mults=[1, 2, 2], condition=True,
+               test_timesteps=500, noise_ensemble=True, spatial_transformer=False, noisetype="simplex")
+    enc = torch.nn.Sequential(torch.nn.Flatten(), torch.nn.LazyLinear(128))
+    mod = M.DDPM_2D(cfg, encoder=enc)
+    assert mod.test_timesteps == 500 and mod.diffusion.num_timesteps == 1000 and mod.diffusion.objective == "pred_x0"
+    assert mod.diffusion.model.image_size == (96, 96) and mod.cfg["cond_dim"] == 128
+    keys = list(mod.state_dict().keys())
+    assert any(k.startswith("diffusion.model.output_blocks.11.0.") for k in keys) and "diffusion.betas" in keys
+    assert mod(torch.zeros(3, 1, 96, 96)).shape == (3, 128)
+    with pytest.raises(ImportError):
+        M.DDPM_2D(dict(cfg))          # timm absent: the encoder must be supplied, nothing is faked
+
+
+def test_library_exports_every_declared_symbol():
+    lib_mod = load_pkg("_lib")
+    header = open(os.path.join(ROOT, "include", "cddpm.h")).read()
+    declared = set(re.findall(r"\b(cddpm_[a-z0-9_]+)\s*\(", header)) - {"cddpm_ctx"}
+    assert declared == set(lib_mod.SYMBOLS), declared ^ set(lib_mod.SYMBOLS)
+    assert os.path.exists(lib_mod.LIB_PATH), "run `python __graft_entry__.py` to build the HIP library"
+    lib = lib_mod.load_library()
+    for name in declared:
+        assert hasattr(lib, name), name
+    # pure host entry point: callable without a GPU
+    d = lib_mod.UnetDesc()
+    d.in_channels = d.out_channels = 1
+    d.model_channels, d.num_levels, d.num_res_blocks, d.head_channels, d.cond_dim = 128, 3, 3, 64, 128
+    d.channel_mult[0], d.channel_mult[1], d.channel_mult[2] = 1, 2, 2
+    d.num_attention_resolutions = 0
+    d.timesteps, d.max_batch, d.max_h, d.max_w = 1000, 64, 128, 128
+    nbytes = lib.cddpm_workspace_bytes(ctypes.byref(d))
+    assert 4e9 < nbytes < 20e9, nbytes               # ~3.4 GB skip stack + 3.2 GB ping-pong + tables + weights
+    d.model_channels = 64
+    assert lib.cddpm_workspace_bytes(ctypes.byref(d)) == 0      # unsupported shape -> refused
+    assert b"model_channels" in lib.cddpm_last_error(None)
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
+def test_engine_fails_loudly_without_gpu():
+    eng = load_pkg("engine")
+    with pytest.raises(RuntimeError, match="no HIP device|MI355X"):
+        eng.CddpmEngine(timesteps=10, max_batch=1, max_h=32, max_w=32)
+
+
+def test_product_never_imports_oracle():
+    pkg_dir = os.path.join(ROOT, "conditioned-diffusion-models-uad_amd")
+    for dirpath, _d, files in os.walk(pkg_dir):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "cddpm_oracle" not in src and "import oracle" not in src and "ref_harness" not in src, f

@@ -1,0 +1,100 @@
+"""CPU: the oracle (oracle/cddpm_oracle.py) against the committed golden vectors, which are outputs of the
+REFERENCE itself (made by oracle/make_golden.py in the build container). Same torch ops, same inputs: the
+expected difference is exactly zero on the same torch build; 2e-6 is allowed for other CPU/torch builds."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLD, golden
+
+TOL = 2e-6
+
+
+def test_manifest_pins_oracle_to_reference():
+    m = json.load(open(os.path.join(GOLD, "MANIFEST.json")))
+    for name, case in m["cases"].items():
+        v = case.get("oracle_vs_reference_maxabs")
+        if isinstance(v, dict):
+            assert all(x <= 1e-6 for x in v.values()), (name, v)
+        elif v is not None:
+            assert v <= 1e-6, (name, v)
+
+
+@pytest.mark.parametrize("T", [1000, 50])
+def test_schedule_buffers(oracle, T):
+    g = golden(f"schedule_T{T}")
+    buf = oracle.schedule_buffers(T)
+    assert set(g.files) == set(buf.keys()) and len(buf) == 13
+    for k in g.files:
+        np.testing.assert_array_equal(buf[k].numpy(), g[k], err_msg=k)
+
+
+def test_schedule_known_answers(oracle):
+    """values measured on the reference"""
+    b = oracle.schedule_buffers(1000)
+    kat = {"betas": {0: 4.12842237e-05, 1: 4.61417512e-05, 500: 0.00315569155, 998: 0.749999404, 999: 0.999000013},
+           "alphas_cumprod": {0: 0.999958694, 500: 0.492285162, 999: 2.42876697e-09},
+           "posterior_mean_coef1": {0: 1.0, 1: 0.527781427, 999: 0.00155689172},
+           "posterior_mean_coef2": {0: 0.0, 1: 0.472218603, 999: 0.0316227004},
+           "posterior_log_variance_clipped": {0: -46.0517006, 1: -10.7340822, 999: -0.00100292673}}
+    for name, d in kat.items():
+        for i, v in d.items():
+            assert abs(float(b[name][i]) - v) <= 2e-7 * max(1.0, abs(v)), (name, i)
+    assert abs(float(oracle.schedule_buffers(50)["betas"][25]) - 0.0630497783) < 1e-8
+
+
+def test_timestep_embedding(oracle):
+    g = golden("timestep_embedding")
+    e = oracle.timestep_embedding(torch.from_numpy(g["t"]), 128).numpy()
+    np.testing.assert_allclose(e, g["emb"], rtol=0, atol=TOL)
+    e1 = oracle.timestep_embedding(torch.tensor([1, 999]), 128)
+    assert abs(float(e1[0, 0]) - 0.540302336) < 1e-7 and abs(float(e1[0, 64]) - 0.841470957) < 1e-7   # cos first
+    assert abs(float(e1[1, 63]) - 0.993353069) < 1e-6 and abs(float(e1[1, 127]) - 0.115106970) < 1e-6
+
+
+def _inputs(synth, B, H, W, slice0=0):
+    return (torch.from_numpy(synth.noise_xT(2, slice0, B, H, W)), torch.from_numpy(synth.synth_cond(1, slice0, B)))
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 32, 32), (1, 64, 96), (1, 96, 96), (1, 128, 128)])
+def test_unet_forward(oracle, synth, sd_torch, B, H, W):
+    g = golden(f"unet_fwd_B{B}_{H}x{W}")
+    x, cond = _inputs(synth, B, H, W)
+    for key in g.files:
+        t = torch.tensor([123, 877][:B]) if key == "tmixed" else torch.full((B,), int(key[1:]))
+        with torch.no_grad():
+            out = oracle.unet_forward(x, t, cond, sd_torch).numpy()
+        assert np.abs(out - g[key]).max() <= TOL, key
+        assert np.abs(g[key]).max() > 0.1      # non-vacuous: the synthetic weights are nowhere zero
+
+
+LOOPS = [("loop_B2_32x32_T1000_start8", 1000, 8, 2, 32, 32, 0),
+         ("loop_B2_32x32_T50_start0", 50, 0, 2, 32, 32, 0),
+         ("loop_B3_32x48_T1000_start5_slice7", 1000, 5, 3, 32, 48, 7),
+         ("loop_B1_128x128_T1000_start50", 1000, 50, 1, 128, 128, 0)]
+if os.environ.get("CDDPM_SLOW"):
+    LOOPS.append(("loop_cfg1_B4_128x128_T50_start0", 50, 0, 4, 128, 128, 0))   # ~4 min on 8 cores
+
+
+@pytest.mark.parametrize("name,T,start_t,B,H,W,slice0", LOOPS, ids=[l[0] for l in LOOPS])
+def test_reverse_loop(oracle, synth, sd_torch, name, T, start_t, B, H, W, slice0):
+    x, cond = _inputs(synth, B, H, W, slice0)
+    buf = oracle.schedule_buffers(T)
+    out = oracle.p_sample_loop(x, cond, sd_torch, buf, lambda t: torch.from_numpy(synth.noise_z(3, t, slice0, B, H, W)),
+                               start_t=start_t).numpy()
+    ref = golden(name)["out"]
+    assert np.abs(out - ref).max() <= TOL
+    assert ref.min() >= 0 and ref.max() <= 1 and ref.std() > 0.01
+
+
+def test_single_step_reconstruction(oracle, synth, sd_torch):
+    g = golden("p_losses_B2_32x32_t499")
+    B, H, W = 2, 32, 32
+    x01 = torch.from_numpy(synth.synth_slices(2, 0, B, H, W))
+    cond = torch.from_numpy(synth.synth_cond(1, 0, B))
+    noise = torch.from_numpy(synth.noise_z(3, 0, 0, B, H, W))
+    loss, reco = oracle.p_losses_recon(x01, torch.full((B,), 499), cond, noise, sd_torch, oracle.schedule_buffers(1000))
+    assert np.abs(reco.numpy() - g["reco"]).max() <= TOL and abs(float(loss) - float(g["loss"])) <= TOL

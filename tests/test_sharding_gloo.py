@@ -1,0 +1,80 @@
+"""CPU, world_size 2 over gloo: the slice sharding + single final gather of sharding.py. The per-chunk
+reconstruction is replaced by a deterministic function of the GLOBAL slice index (what the real path
+guarantees through the counter RNG), so the test checks partitioning, chunking, padding and the collective."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import PKG_NAME, ROOT
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _fake_reco(slice0, count, H=8, W=12):
+    idx = torch.arange(slice0, slice0 + count, dtype=torch.float32).reshape(count, 1, 1, 1)
+    return (idx * 0.5 + torch.arange(H * W, dtype=torch.float32).reshape(1, 1, H, W) * 1e-3).contiguous()
+
+
+def _worker(rank, world, port, n_slices, chunk, mode, q):
+    import importlib
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sh = importlib.import_module(PKG_NAME + ".sharding")
+    calls = []
+
+    def run(s0, cnt):
+        calls.append((s0, cnt))
+        return _fake_reco(s0, cnt)
+
+    out = sh.reconstruct_sharded(n_slices, (8, 12), run, chunk=chunk, gather=mode)
+    q.put((rank, calls, None if out is None else out.clone()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_slices,chunk,mode", [(8, 3, "all"), (7, 2, "all"), (5, 64, "root"), (1, 4, "all")])
+def test_two_rank_shard_and_gather(n_slices, chunk, mode):
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_slices, chunk, mode, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        r, calls, out = q.get(timeout=120)
+        res[r] = (calls, out)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    expect = _fake_reco(0, n_slices)
+    covered = sorted(s for r in res for (s0, c) in res[r][0] for s in range(s0, s0 + c))
+    assert covered == list(range(n_slices))                       # every slice exactly once
+    assert all(c <= chunk for r in res for (_s, c) in res[r][0])
+    assert torch.equal(res[0][1], expect)                         # identical to the 1-rank result, bitwise
+    if mode == "all":
+        assert torch.equal(res[1][1], expect)
+    else:
+        assert res[1][1] is None
+
+
+def test_shard_range_partition():
+    import importlib
+    sh = importlib.import_module(PKG_NAME + ".sharding")
+    for n in (0, 1, 7, 8, 8192):
+        for w in (1, 2, 3, 8):
+            rs = [sh.shard_range(n, r, w) for r in range(w)]
+            assert rs[0][0] == 0 and rs[-1][1] == n and all(rs[i][1] == rs[i + 1][0] for i in range(w - 1))
+            assert max(b - a for a, b in rs) - min(b - a for a, b in rs) <= 1
