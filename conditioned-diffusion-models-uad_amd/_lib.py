@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libcddpm_hip.so")
+LIB_PATH = os.environ.get("CDDPM_LIB") or os.path.join(_HERE, "csrc", "libcddpm_hip.so")   # CDDPM_LIB: A/B builds (tools/)
 
 CDDPM_MAX_LEVELS = 8
 
@@ -60,6 +60,8 @@ SYMBOLS = {
     "cddpm_set_tap": (_i, [_vp, _i, _fp]),
     "cddpm_block_shape": (_i, [_vp, _i, _i, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
     "cddpm_op_conv": (_i, [_vp, _fp, _i, _fp, _i, _fp, _i, _i, _fp, _fp, _i, _i, _fp, _i, _fp, _i, _i, _i, _vp]),
+    "cddpm_op_conv_bench": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, C.POINTER(C.c_double),
+                                 C.POINTER(_u64)]),
     "cddpm_op_gn_coef": (_i, [_vp, _fp, _i, _fp, _i, _fp, _fp, _fp, _fp, _i, _i, _vp]),
     "cddpm_op_attention": (_i, [_vp, _fp, _fp, _i, _i, _i, _vp]),
 }

@@ -32,15 +32,18 @@ def lib_is_current() -> bool:
     return all(os.path.getmtime(d) <= t for d in deps if os.path.exists(d))
 
 
-def build_lib(force: bool = False, verbose: bool = False) -> str:
-    if not force and lib_is_current():
+def build_lib(force: bool = False, verbose: bool = False, defines=(), tag: str = "") -> str:
+    """defines/tag: experimental A/B builds, e.g. defines=["CDDPM_STAMPS"], tag="stamps" -> libcddpm_hip_stamps.so
+    (loaded through the CDDPM_LIB environment variable by tools/conv_ab.py); the product build has neither."""
+    lib_out = LIB if not tag else LIB.replace(".so", f"_{tag}.so")
+    if not force and not tag and lib_is_current():
         return LIB
     hipcc = _hipcc()
-    flags = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+    flags = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"] + [f"-D{d}" for d in defines]
     objs = []
 
     def compile_one(src):
-        obj = os.path.join(CSRC, src.replace(".hip", ".o"))
+        obj = os.path.join(CSRC, src.replace(".hip", f"{('_' + tag) if tag else ''}.o"))
         cmd = [hipcc, *flags, "-c", os.path.join(CSRC, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
@@ -51,10 +54,10 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
 
     with ThreadPoolExecutor(max_workers=min(5, os.cpu_count() or 1)) as ex:
         objs = list(ex.map(compile_one, SOURCES))
-    r = subprocess.run([hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB, *objs], capture_output=True, text=True)
+    r = subprocess.run([hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", lib_out, *objs], capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc link failed:\n{r.stderr}")
-    return LIB
+    return lib_out
 
 
 if __name__ == "__main__":

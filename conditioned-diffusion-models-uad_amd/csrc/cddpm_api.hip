@@ -935,6 +935,65 @@ int cddpm_op_conv(cddpm_handle h, const float* src0, int C0, const float* src1, 
     return 0;
 }
 
+int cddpm_op_conv_bench(cddpm_handle h, int C0, int C1, int Cout, int ksize, int B, int H, int W, int use_coef, int silu,
+                        int upsample, int res_mode, int skipC, int iters, double* ms_out, uint64_t* stamps_out) {
+    if (!h) return -1;
+    const int Cin = C0 + C1, taps = ksize * ksize;
+    if ((ksize != 1 && ksize != 3) || C0 % 32 || C1 % 32 || Cin <= 0 || Cout % 128 || skipC % 32)
+        return fail(h, "cddpm_op_conv_bench: unsupported shape");
+    HIPCHECK(h, hipSetDevice(h->device));
+    hipStream_t s = nullptr;
+    const int sh = upsample ? H / 2 : H, sw = upsample ? W / 2 : W;
+    const size_t n0 = (size_t)B * sh * sw * C0, n1 = (size_t)B * sh * sw * C1, nout = (size_t)B * H * W * Cout;
+    const size_t nsk = (size_t)B * H * W * skipC, nw = (size_t)Cout * Cin * taps, nws = (size_t)Cout * skipC;
+    const size_t nres = res_mode == 2 ? nout / 4 : nout;
+    float *x0 = nullptr, *x1 = nullptr, *out = nullptr, *res = nullptr, *sk = nullptr, *w = nullptr, *ws = nullptr, *cf = nullptr, *bs = nullptr;
+    unsigned long long* stamps = nullptr;
+    auto alloc_fill = [&](float** p, size_t n, uint32_t stream_id, float scale) -> int {
+        if (!n) return 0;
+        const size_t n4 = (n + 3) / 4 * 4;
+        if (hipMalloc((void**)p, n4 * sizeof(float)) != hipSuccess) return -1;
+        launch_noise_fill(*p, 1234, stream_id, 0, 0, 1, (int)n4, s);
+        (void)scale;
+        return 0;
+    };
+    int rc = 0;
+    rc |= alloc_fill(&x0, n0, 1, 1.f); rc |= alloc_fill(&x1, n1, 2, 1.f); rc |= alloc_fill(&sk, nsk, 3, 1.f);
+    rc |= alloc_fill(&w, nw, 4, 1.f); rc |= alloc_fill(&ws, nws, 5, 1.f); rc |= alloc_fill(&cf, (size_t)3 * B * Cin, 6, 1.f);
+    rc |= alloc_fill(&bs, Cout, 7, 1.f);
+    if (res_mode) rc |= alloc_fill(&res, nres, 8, 1.f);
+    if (hipMalloc((void**)&out, nout * sizeof(float)) != hipSuccess) rc = -1;
+    if (hipMalloc((void**)&stamps, 64 * sizeof(unsigned long long)) != hipSuccess) rc = -1;
+    if (rc) return fail(h, "cddpm_op_conv_bench: allocation failed");
+    HIPCHECK(h, hipMemset(stamps, 0, 64 * sizeof(unsigned long long)));
+    ConvArgs a;
+    zero_conv_args(a);
+    a.src0 = x0; a.C0 = C0; a.src1 = x1; a.C1 = C1; a.srcH = sh; a.srcW = sw; a.upsample = upsample;
+    a.coef = use_coef ? cf : nullptr; a.silu = silu; a.wpk = w; a.bias = bs; a.res = res; a.res_up = (res_mode == 2);
+    a.out = out; a.B = B; a.H = H; a.W = W; a.Cout = Cout; a.taps = taps;
+    a.skip0 = sk; a.S0 = skipC; a.skip_wpk = ws;
+    a.stamps = nullptr;
+    hipEvent_t e0, e1;
+    HIPCHECK(h, hipEventCreate(&e0));
+    HIPCHECK(h, hipEventCreate(&e1));
+    launch_conv(a, s);   // warm-up
+    a.stamps = stamps_out ? stamps : nullptr;
+    HIPCHECK(h, hipEventRecord(e0, s));
+    for (int i = 0; i < iters; ++i) launch_conv(a, s);
+    HIPCHECK(h, hipEventRecord(e1, s));
+    HIPCHECK(h, hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIPCHECK(h, hipEventElapsedTime(&ms, e0, e1));
+    if (ms_out) *ms_out = ms / iters;
+    if (stamps_out) HIPCHECK(h, hipMemcpy(stamps_out, stamps, 64 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIPCHECK(h, hipGetLastError());
+    for (void* p : {(void*)x0, (void*)x1, (void*)out, (void*)res, (void*)sk, (void*)w, (void*)ws, (void*)cf, (void*)bs, (void*)stamps})
+        if (p) (void)hipFree(p);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return 0;
+}
+
 int cddpm_op_gn_coef(cddpm_handle h, const float* src0, int C0, const float* src1, int C1, const float* gamma_host,
                      const float* beta_host, const float* film_dev, float* coef_dev, int B, int HW, void* stream) {
     if (!h) return -1;

@@ -25,9 +25,21 @@ namespace cddpm {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float v4f __attribute__((ext_vector_type(4)));   // native vector: stays in registers (HIP's float4 struct arrays may not)
 
+#ifdef CDDPM_STAMPS
+// phase accounting for diagnostic builds: 0 prologue, 1 patch stage (barrier + transform + ds_write), 2 weight stage
+// (ds_write + prefetch issue + barrier), 3 MFMA compute, 4 chunk fold, 5 epilogue
+#define STAMP(i) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); st_[i] += now_ - last_; last_ = now_; }
+#else
+#define STAMP(i)
+#endif
+
 __device__ __forceinline__ float silu_f(float v) {
-    // v * sigmoid(v); accurate expf (<= 1 ulp) + v_rcp_f32 (1 ulp); exp(+large) = inf -> rcp = 0, no NaN
-    return v * __builtin_amdgcn_rcpf(1.0f + expf(-v));
+    // v * sigmoid(v); exp(+large) = inf -> rcp = 0, no NaN
+#ifdef CDDPM_ACCURATE_SILU
+    return v * __builtin_amdgcn_rcpf(1.0f + expf(-v));       // ocml expf (<= 1 ulp), ~20 VALU
+#else
+    return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));     // v_exp_f32 path (~3 ulp on the exp), 6 VALU
+#endif
 }
 
 template <int TAPS>
@@ -45,6 +57,10 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
+#ifdef CDDPM_STAMPS
+    unsigned long long st_[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long last_ = __builtin_amdgcn_s_memtime();
+#endif
     const int li = lane & 31;
     const int lh = lane >> 5;
     const int wm = wave & 1;    // pixel rows {0,1} | {2,3}
@@ -211,11 +227,13 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
     }
     load_act(0);
     int buf = 0;
+    STAMP(0)
     for (int chunk = 0; chunk < nch; ++chunk) {
         const bool main_seg = chunk < nch_main;
         const int ntap = main_seg ? TAPS : 1;
         __syncthreads();   // every wave is done reading the previous patch
         store_act(chunk);
+        STAMP(1)
         for (int t = 0; t < ntap; ++t) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) ldsW[buf * 1024 + tid + 256 * i] = wreg[i];
@@ -225,8 +243,10 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
             for (int i = 0; i < 4; ++i) wreg[i] = pn[tid + 256 * i];
             if (last_tap && chunk + 1 < nch) load_act(chunk + 1);
             __syncthreads();
+            STAMP(2)
             compute(main_seg ? t : (TAPS / 2), buf);   // skip segment: centre tap
             buf ^= 1;
+            STAMP(3)
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -236,6 +256,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
             }
+        STAMP(4)
     }
 
     // ---- epilogue: D row = pixel (r&3) + 8 (r>>2) + 4 lh, D col = cout li
@@ -262,6 +283,11 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
             }
         }
     }
+#ifdef CDDPM_STAMPS
+    STAMP(5)
+    if (a.stamps && lane == 0)
+        for (int i = 0; i < 6; ++i) atomicAdd(&a.stamps[wave * 8 + i], st_[i]);
+#endif
 }
 
 void launch_conv(const ConvArgs& a, hipStream_t stream) {

@@ -29,6 +29,7 @@ struct ConvArgs {
     // used for ResBlock skip_connection convs: out += conv1x1(skip0|skip1) (bias folded by the caller)
     const float* skip0; const float* skip1; int S0, S1;   // NHWC at the OUTPUT resolution
     const float* skip_wpk;
+    unsigned long long* stamps;   // diagnostic builds (-DCDDPM_STAMPS) only: per-wave phase cycle sums, else nullptr
 };
 void launch_conv(const ConvArgs& a, hipStream_t stream);
 

@@ -151,6 +151,14 @@ int cddpm_op_conv(cddpm_handle h, const float* src0_dev, int C0, const float* sr
                   const float* res_dev, int res_upsample,
                   float* out_dev, int B, int H, int W, void* stream);
 
+/* micro-benchmark of the fused conv kernel on device-generated N(0,1) data (no result check): average ms per
+ * launch over `iters` launches; res_mode 0 none, 1 same resolution, 2 half resolution; skipC = channels of a fused
+ * 1x1 skip_connection segment (0 = none). stamps_out (64 x uint64, may be NULL) receives per-wave phase cycle sums
+ * in diagnostic builds (-DCDDPM_STAMPS), zeros otherwise. */
+int cddpm_op_conv_bench(cddpm_handle h, int C0, int C1, int Cout, int ksize, int B, int H, int W, int use_coef,
+                        int silu, int upsample, int res_mode, int skipC, int iters, double* ms_out,
+                        uint64_t* stamps_out);
+
 /* standalone GroupNorm(32) statistics + coefficient kernel pair: coef_dev [3][B][C] (mean, a, d) with
  * a = rstd*gamma*(1+scale), d = beta*(1+scale)+shift; film_dev = [B][2C] (scale | shift) or NULL. */
 int cddpm_op_gn_coef(cddpm_handle h, const float* src0_dev, int C0, const float* src1_dev, int C1,

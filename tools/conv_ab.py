@@ -1,0 +1,85 @@
+#!/usr/bin/env python3
+"""A/B micro-benchmark of the fused conv kernel across library builds (guide rule: compare variants on one
+device, random data). Build variants in the container first:
+    python tools/conv_ab.py --build base: stamps:CDDPM_STAMPS accsilu:CDDPM_ACCURATE_SILU
+then on the GPU box:
+    python tools/conv_ab.py --run base stamps accsilu
+Each variant runs in its own process (CDDPM_LIB selects the .so); shapes are the UNet's layers at B=64."""
+import ctypes as C
+import importlib
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+PKG = "conditioned-diffusion-models-uad_amd"
+CSRC = os.path.join(ROOT, PKG, "csrc")
+
+# name, C0, C1, Cout, k, H, W, coef, silu, up, res_mode, skipC
+SHAPES = [
+    ("conv1 128>128 @128", 128, 0, 128, 3, 128, 128, 1, 1, 0, 0, 0),
+    ("conv2 128>128 @128 +res", 128, 0, 128, 3, 128, 128, 1, 1, 0, 1, 0),
+    ("plain 128>128 @128 nocoef", 128, 0, 128, 3, 128, 128, 0, 0, 0, 0, 0),
+    ("up conv1 256>256 @128", 256, 0, 256, 3, 128, 128, 1, 1, 1, 0, 0),
+    ("cat conv1 512>256 @64", 256, 256, 256, 3, 64, 64, 1, 1, 0, 0, 0),
+    ("conv2 256>256 @64 +skip512", 256, 0, 256, 3, 64, 64, 1, 1, 0, 0, 512),
+    ("conv 256>256 @32", 256, 0, 256, 3, 32, 32, 1, 1, 0, 0, 0),
+    ("cat conv1 384>128 @128", 256, 128, 128, 3, 128, 128, 1, 1, 0, 0, 0),
+]
+PHASES = ["prologue", "patch stage", "weight stage", "mfma compute", "chunk fold", "epilogue"]
+
+
+def child(B, iters):
+    lib = importlib.import_module(PKG + "._lib").load_library()
+    eng = importlib.import_module(PKG + ".engine")
+    e = eng.CddpmEngine(timesteps=10, max_batch=1, max_h=32, max_w=32)
+    out = []
+    for (name, C0, C1, Cout, k, H, W, coef, silu, up, res, sk) in SHAPES:
+        ms = C.c_double()
+        st = (C.c_uint64 * 64)()
+        rc = lib.cddpm_op_conv_bench(e._h, C0, C1, Cout, k, B, H, W, coef, silu, up, res, sk, iters, C.byref(ms), st)
+        assert rc == 0, lib.cddpm_last_error(e._h)
+        flops = 2.0 * B * H * W * Cout * ((C0 + C1) * k * k + sk)
+        row = {"shape": name, "ms": ms.value, "tflops": flops / ms.value / 1e9}
+        tot = [sum(st[w * 8 + i] for w in range(4)) for i in range(6)]
+        if sum(tot):
+            row["phase_share"] = {p: round(t / sum(tot), 4) for p, t in zip(PHASES, tot)}
+        out.append(row)
+    print(json.dumps(out))
+
+
+def main():
+    if sys.argv[1] == "--build":
+        b = importlib.import_module(PKG + ".build")
+        for spec in sys.argv[2:]:
+            tag, _, defs = spec.partition(":")
+            print(b.build_lib(force=True, defines=[d for d in defs.split(",") if d], tag=tag))
+    elif sys.argv[1] == "--child":
+        child(int(sys.argv[2]), int(sys.argv[3]))
+    elif sys.argv[1] == "--run":
+        B = int(os.environ.get("AB_BATCH", "64"))
+        rounds = int(os.environ.get("AB_ROUNDS", "2"))
+        res = {}
+        for r in range(rounds):          # interleaved rounds
+            for tag in sys.argv[2:]:
+                env = dict(os.environ, CDDPM_LIB=os.path.join(CSRC, f"libcddpm_hip_{tag}.so"))
+                o = subprocess.run([sys.executable, __file__, "--child", str(B), "5"], env=env, capture_output=True, text=True)
+                if o.returncode != 0:
+                    print(tag, "FAILED", o.stderr[-2000:])
+                    continue
+                res.setdefault(tag, []).append(json.loads(o.stdout.strip().splitlines()[-1]))
+        for i, shp in enumerate(SHAPES):
+            print(shp[0])
+            for tag, runs in res.items():
+                ms = [r[i]["ms"] for r in runs]
+                tf = [r[i]["tflops"] for r in runs]
+                line = f"   {tag:10s} ms min {min(ms):8.3f} med {sorted(ms)[len(ms) // 2]:8.3f}  TF max {max(tf):6.1f}"
+                if "phase_share" in runs[0][i]:
+                    line += "  " + json.dumps(runs[0][i]["phase_share"])
+                print(line)
+
+
+if __name__ == "__main__":
+    main()
