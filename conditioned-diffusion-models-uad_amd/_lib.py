@@ -82,6 +82,9 @@ def load_library(path: str = LIB_PATH):
         raise CddpmLibraryError(
             f"{path} not found: the HIP extension is not built. Run `python __graft_entry__.py` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback for this path.")
+    # torch must come first: it ships its own libamdhip64 / libhsa-runtime64, and the process must end up with
+    # ONE HIP runtime. Loaded first, ours would pull /opt/rocm's copy in and torch would then see no device.
+    import torch  # noqa: F401
     try:
         lib = C.CDLL(path)
     except OSError as e:

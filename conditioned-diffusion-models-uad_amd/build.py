@@ -32,7 +32,7 @@ def lib_is_current() -> bool:
     return all(os.path.getmtime(d) <= t for d in deps if os.path.exists(d))
 
 
-def build_lib(force: bool = False, verbose: bool = False, defines=(), tag: str = "") -> str:
+def build_lib(force: bool = False, verbose: bool = False, defines=(), tag: str = "", conv_src: str = "") -> str:
     """defines/tag: experimental A/B builds, e.g. defines=["CDDPM_STAMPS"], tag="stamps" -> libcddpm_hip_stamps.so
     (loaded through the CDDPM_LIB environment variable by tools/conv_ab.py); the product build has neither."""
     lib_out = LIB if not tag else LIB.replace(".so", f"_{tag}.so")
@@ -44,7 +44,8 @@ def build_lib(force: bool = False, verbose: bool = False, defines=(), tag: str =
 
     def compile_one(src):
         obj = os.path.join(CSRC, src.replace(".hip", f"{('_' + tag) if tag else ''}.o"))
-        cmd = [hipcc, *flags, "-c", os.path.join(CSRC, src), "-o", obj]
+        path = conv_src if (conv_src and src == "conv_mfma.hip") else os.path.join(CSRC, src)   # A/B of older conv kernels
+        cmd = [hipcc, *flags, f"-I{CSRC}", "-c", path, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}:\n{r.stderr}")

@@ -95,8 +95,11 @@ struct cddpm_ctx {
     std::vector<size_t> hs_elems;
     float *bufA = nullptr, *bufB = nullptr, *bufH = nullptr, *bufP0 = nullptr, *bufP1 = nullptr;
     float *qkvbuf = nullptr, *attbuf = nullptr, *headP = nullptr, *model_out = nullptr;
-    double* gn_part = nullptr;
     float* coef = nullptr;
+    // GroupNorm statistics records per activation buffer (written by the producing conv's epilogue, or by the
+    // stand-alone sweep): buffer -> records storage, and how many records are valid in the current forward
+    std::map<const float*, float*> stat_buf;
+    std::map<const float*, int> stat_n;
     float *scratch0 = nullptr, *scratch1 = nullptr;   // [max(T,Bmax)][half] for the embedding MLPs
     int max_nsplit = 0;
 
@@ -152,9 +155,14 @@ double conv_bytes(const ConvArgs& a) {
     b += (double)a.Cout * ((double)(a.C0 + a.C1) * a.taps + a.S0 + a.S1);
     return 4.0 * b;
 }
-void conv_launch(cddpm_ctx* h, const ConvArgs& a, hipStream_t s) {
-    Prof p(h, a.taps == 9 ? PC_CONV3 : PC_CONV1, conv_flops(a), conv_bytes(a), s);
-    launch_conv(a, s);
+void conv_launch(cddpm_ctx* h, ConvArgs a, hipStream_t s) {
+    auto it = h->stat_buf.find(a.out);       // outputs that can feed a GroupNorm get their statistics for free
+    a.stats = (it != h->stat_buf.end()) ? it->second : nullptr;
+    {
+        Prof p(h, a.taps == 9 ? PC_CONV3 : PC_CONV1, conv_flops(a), conv_bytes(a), s);
+        launch_conv(a, s);
+    }
+    if (a.stats) h->stat_n[a.out] = conv_stat_records(a.H, a.W);
 }
 
 #define HIPCHECK(h, call)                                                                      \
@@ -376,13 +384,30 @@ size_t plan_workspace(cddpm_ctx* h, bool do_alloc, int* rc) {
     want(&h->attbuf, maxatt);
     want(&h->headP, B * HW * 9);
     want(&h->model_out, B * HW);
-    size_t max_rec = 1;   // max over B' <= max_batch of B' * nsplit(B'): records of one GroupNorm sweep
-    for (int b = 1; b <= d.max_batch; ++b) max_rec = std::max(max_rec, (size_t)b * gn_nsplit(b, (int)HW));
     h->max_nsplit = gn_nsplit(1, (int)HW);
     {
-        const size_t elems = max_rec * maxC * 2;
-        total += elems * sizeof(double);
-        if (do_alloc && *rc == 0) *rc = dev_alloc(h, &h->gn_part, elems);
+        // statistics records: [B][records][C][2] fp32 per buffer that can feed a GroupNorm
+        auto nrec_at = [&](int ds) {
+            const int hh = d.max_h / ds, ww = d.max_w / ds;
+            return std::max(conv_stat_records(hh, ww), gn_nsplit(1, hh * ww));
+        };
+        size_t pi = 0;
+        for (const Op& op : h->prog)
+            if (op.push) {
+                const BlockInfo& bi = h->blocks[op.block];
+                float* sp = nullptr;
+                want(&sp, B * (size_t)nrec_at(bi.ds) * bi.C * 2);
+                if (do_alloc) h->stat_buf[h->hs[pi]] = sp;
+                ++pi;
+            }
+        size_t maxrc = 0;
+        for (const BlockInfo& bi : h->blocks) maxrc = std::max(maxrc, (size_t)nrec_at(bi.ds) * bi.C);
+        float* work[3] = {h->bufA, h->bufB, h->bufH};
+        for (int i = 0; i < 3; ++i) {
+            float* sp = nullptr;
+            want(&sp, B * maxrc * 2);
+            if (do_alloc) h->stat_buf[work[i]] = sp;
+        }
     }
     want(&h->coef, 3 * B * maxC);
     // tables and embedding scratch
@@ -429,14 +454,29 @@ int upload_conv(cddpm_ctx* h, const HostWeights& hw, const std::string& p, int C
     return 0;
 }
 
+// statistics records of a tensor for the current forward: fused by its producer, else swept here once
+const float* stats_of(cddpm_ctx* h, const float* x, int C, int B, int HW, int* n, hipStream_t s) {
+    auto it = h->stat_n.find(x);
+    float* rec = h->stat_buf.at(x);
+    if (it == h->stat_n.end()) {
+        const int ns = gn_nsplit(B, HW);
+        Prof p(h, PC_GN, 0.0, 4.0 * B * (double)HW * C, s);
+        launch_gn_partial(x, C, B, HW, ns, rec, s);
+        h->stat_n[x] = ns;
+        *n = ns;
+    } else {
+        *n = it->second;
+    }
+    return rec;
+}
+
 void gn_coef(cddpm_ctx* h, const float* x0, int C0, const float* x1, int C1, int B, int HW, const NormW& nw,
              bool film, int eoff, hipStream_t s) {
-    const int Ct = C0 + C1;
-    const int ns = gn_nsplit(B, HW);
-    Prof p(h, PC_GN, 0.0, 4.0 * B * (double)HW * Ct, s);
-    launch_gn_partial(x0, C0, Ct, 0, B, HW, ns, h->gn_part, s);
-    if (x1) launch_gn_partial(x1, C1, Ct, C0, B, HW, ns, h->gn_part, s);
-    launch_gn_finalize(h->gn_part, ns, Ct, B, HW, nw.gamma, nw.beta, film ? h->tab : nullptr, h->cpart, h->sumE, eoff,
+    int n0 = 0, n1 = 0;
+    const float* r0 = stats_of(h, x0, C0, B, HW, &n0, s);
+    const float* r1 = x1 ? stats_of(h, x1, C1, B, HW, &n1, s) : nullptr;
+    Prof p(h, PC_GN, 0.0, 8.0 * B * ((double)n0 * C0 + (double)n1 * C1), s);
+    launch_gn_finalize(r0, C0, n0, r1, C1, n1, B, HW, nw.gamma, nw.beta, film ? h->tab : nullptr, h->cpart, h->sumE, eoff,
                        h->d_t, nullptr, h->coef, s);
 }
 
@@ -522,6 +562,7 @@ int check_call(cddpm_ctx* h, int B, int H, int W) {
 
 // UNetModel.forward (OpenAI_Unet.py:823-1006); d_t must hold the per-sample timesteps.
 int forward_impl(cddpm_ctx* h, const float* x, float* out, int B, int H, int W, hipStream_t s) {
+    h->stat_n.clear();        // no tensor of this forward has statistics yet
     std::vector<int> stack;   // indices into h->hs
     int npush = 0;
     const float* cur = nullptr;
@@ -1002,19 +1043,21 @@ int cddpm_op_gn_coef(cddpm_handle h, const float* src0, int C0, const float* src
     hipStream_t s = (hipStream_t)stream;
     HIPCHECK(h, hipSetDevice(h->device));
     const int ns = gn_nsplit(B, HW);
-    double* part = nullptr;
-    float *g = nullptr, *bt = nullptr;
-    HIPCHECK(h, hipMalloc((void**)&part, (size_t)B * ns * C * 2 * sizeof(double)));
+    float *rec0 = nullptr, *rec1 = nullptr, *g = nullptr, *bt = nullptr;
+    HIPCHECK(h, hipMalloc((void**)&rec0, (size_t)B * ns * C0 * 2 * sizeof(float)));
+    if (src1) HIPCHECK(h, hipMalloc((void**)&rec1, (size_t)B * ns * C1 * 2 * sizeof(float)));
     HIPCHECK(h, hipMalloc((void**)&g, (size_t)C * sizeof(float)));
     HIPCHECK(h, hipMalloc((void**)&bt, (size_t)C * sizeof(float)));
     HIPCHECK(h, hipMemcpy(g, gamma_host, (size_t)C * sizeof(float), hipMemcpyHostToDevice));
     HIPCHECK(h, hipMemcpy(bt, beta_host, (size_t)C * sizeof(float), hipMemcpyHostToDevice));
-    launch_gn_partial(src0, C0, C, 0, B, HW, ns, part, s);
-    if (src1) launch_gn_partial(src1, C1, C, C0, B, HW, ns, part, s);
-    launch_gn_finalize(part, ns, C, B, HW, g, bt, nullptr, nullptr, 0, 0, nullptr, film_dev, coef_dev, s);
+    launch_gn_partial(src0, C0, B, HW, ns, rec0, s);
+    if (src1) launch_gn_partial(src1, C1, B, HW, ns, rec1, s);
+    launch_gn_finalize(rec0, C0, ns, rec1, C1, src1 ? ns : 0, B, HW, g, bt, nullptr, nullptr, 0, 0, nullptr, film_dev,
+                       coef_dev, s);
     HIPCHECK(h, hipGetLastError());
     HIPCHECK(h, hipStreamSynchronize(s));
-    (void)hipFree(part);
+    (void)hipFree(rec0);
+    if (rec1) (void)hipFree(rec1);
     (void)hipFree(g);
     (void)hipFree(bt);
     return 0;

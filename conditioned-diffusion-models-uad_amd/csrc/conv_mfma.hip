@@ -34,12 +34,16 @@ typedef float v4f __attribute__((ext_vector_type(4)));   // native vector: stays
 #endif
 
 __device__ __forceinline__ float silu_f(float v) {
-    // v * sigmoid(v); exp(+large) = inf -> rcp = 0, no NaN
-#ifdef CDDPM_ACCURATE_SILU
-    return v * __builtin_amdgcn_rcpf(1.0f + expf(-v));       // ocml expf (<= 1 ulp), ~20 VALU
-#else
-    return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));     // v_exp_f32 path (~3 ulp on the exp), 6 VALU
-#endif
+    // v * sigmoid(v). exp(-v) = 2^t with t = -v log2(e) carried as (t, tl): the rounding error of the product is
+    // recovered with two fmas and applied as a first-order correction, so the result is good to ~1.5 ulp on the
+    // v_exp_f32 / v_rcp_f32 pair at 9 VALU ops (ocml expf: ~20). t is clamped so 2^t stays finite (no inf * 0).
+    const float t = fminf(-v * 1.44269502162933349609375f, 126.0f);
+    float tl = __builtin_fmaf(-v, 1.44269502162933349609375f, -t);
+    tl = __builtin_fmaf(-v, 1.925963033500011e-08f, tl);
+    tl = (t < 126.0f) ? tl : 0.0f;
+    float e = __builtin_amdgcn_exp2f(t);
+    e = __builtin_fmaf(e, tl * 0.693147180559945f, e);
+    return v * __builtin_amdgcn_rcpf(1.0f + e);
 }
 
 template <int TAPS>
@@ -259,28 +263,74 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
         STAMP(4)
     }
 
-    // ---- epilogue: D row = pixel (r&3) + 8 (r>>2) + 4 lh, D col = cout li
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-        const int y = y0 + 2 * wm + mt;
-        if (y >= a.H) continue;
+    __syncthreads();   // every wave is done with the patch / weight buffers before they become transpose space
+    // ---- epilogue. The accumulator layout (D row = pixel (r&3) + 8 (r>>2) + 4 lh, D col = cout li) would give
+    //      4-byte stores and one dependent residual load per store; instead each wave transposes its 64 x 64 tile
+    //      through a private 8-KB LDS region (patch buffers are dead after the last barrier), one 32-channel half
+    //      at a time, so that every lane moves 16 B and every wave instruction covers eight full 128-B lines:
+    //      all residual loads of a half are in flight before the first add.
+    {
+        float* tr = reinterpret_cast<float*>(lds) + wave * 2048;      // [64 pixels][32 channels]
+        const int cq = lane & 7;                                      // channel quad of this lane in the read phase
+        const int prow = lane >> 3;                                   // pixel row within a group of 8
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
-            const int co = cb * 128 + 64 * wn + 32 * nt + li;
-            const float bias = a.bias ? a.bias[co] : 0.f;
+            const int co = cb * 128 + 64 * wn + 32 * nt + 4 * cq;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int x = x0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (x < a.W) {
-                    float v = tot[mt][nt][r] + bias;
-                    if (a.res) {
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    tr[(mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * 32 + li] = tot[mt][nt][r];
+            __builtin_amdgcn_wave_barrier();
+            const v4f bias = a.bias ? *reinterpret_cast<const v4f*>(a.bias + co) : v4f{0.f, 0.f, 0.f, 0.f};
+            v4f ssum = v4f{0.f, 0.f, 0.f, 0.f}, ssq = ssum;
+#pragma unroll
+            for (int hb = 0; hb < 2; ++hb) {          // two batches of 4 pixel rows: bounds the live registers
+                v4f val[4], rsd[4];
+                size_t oidx[4];
+                bool ok[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int p = 8 * (4 * hb + i) + prow;                // 0..63: tile pixel (row p>>5, column p&31)
+                    const int y = y0 + 2 * wm + (p >> 5), x = x0 + (p & 31);
+                    ok[i] = (y < a.H) && (x < a.W);
+                    oidx[i] = ((size_t)(b * a.H + y) * a.W + x) * a.Cout + co;
+                    rsd[i] = v4f{0.f, 0.f, 0.f, 0.f};
+                    if (a.res && ok[i]) {
                         const size_t rp = a.res_up ? ((size_t)(b * (a.H >> 1) + (y >> 1)) * (a.W >> 1) + (x >> 1))
                                                    : ((size_t)(b * a.H + y) * a.W + x);
-                        v += a.res[rp * a.Cout + co];
+                        rsd[i] = *reinterpret_cast<const v4f*>(a.res + rp * a.Cout + co);
                     }
-                    a.out[((size_t)(b * a.H + y) * a.W + x) * a.Cout + co] = v;
+                    val[i] = *reinterpret_cast<const v4f*>(tr + p * 32 + 4 * cq);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (ok[i]) {
+                        const v4f o = val[i] + bias + rsd[i];
+                        *reinterpret_cast<v4f*>(a.out + oidx[i]) = o;
+                        ssum += o;
+                        ssq += o * o;
+                    }
+            }
+            // GroupNorm statistics of the tensor just written, for the NEXT GroupNorm: per-channel sums over this
+            // wave's 64 pixels (8 in-lane values, then the 8 lanes sharing a channel quad), one record per wave tile
+            if (a.stats) {
+#pragma unroll
+                for (int m = 8; m < 64; m <<= 1) {
+                    ssum.x += __shfl_xor(ssum.x, m, 64); ssum.y += __shfl_xor(ssum.y, m, 64);
+                    ssum.z += __shfl_xor(ssum.z, m, 64); ssum.w += __shfl_xor(ssum.w, m, 64);
+                    ssq.x += __shfl_xor(ssq.x, m, 64); ssq.y += __shfl_xor(ssq.y, m, 64);
+                    ssq.z += __shfl_xor(ssq.z, m, 64); ssq.w += __shfl_xor(ssq.w, m, 64);
+                }
+                if (prow == 0) {
+                    const int nrec = 2 * tilesX * tilesY;
+                    const int rec = 2 * (ty * tilesX + tx) + wm;
+                    float* o = a.stats + (((size_t)b * nrec + rec) * a.Cout + co) * 2;
+                    *reinterpret_cast<v4f*>(o) = v4f{ssum.x, ssq.x, ssum.y, ssq.y};
+                    *reinterpret_cast<v4f*>(o + 4) = v4f{ssum.z, ssq.z, ssum.w, ssq.w};
                 }
             }
+            __builtin_amdgcn_wave_barrier();
         }
     }
 #ifdef CDDPM_STAMPS

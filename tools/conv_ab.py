@@ -54,8 +54,9 @@ def main():
     if sys.argv[1] == "--build":
         b = importlib.import_module(PKG + ".build")
         for spec in sys.argv[2:]:
-            tag, _, defs = spec.partition(":")
-            print(b.build_lib(force=True, defines=[d for d in defs.split(",") if d], tag=tag))
+            tag, _, rest = spec.partition(":")
+            defs, _, src = rest.partition("@")          # tag:DEF1,DEF2@path/to/alternative_conv_mfma.hip
+            print(b.build_lib(force=True, defines=[d for d in defs.split(",") if d], tag=tag, conv_src=src))
     elif sys.argv[1] == "--child":
         child(int(sys.argv[2]), int(sys.argv[3]))
     elif sys.argv[1] == "--run":
