@@ -36,6 +36,8 @@ struct ConvArgs {
 };
 inline int conv_stat_records(int H, int W) { return 2 * ((W + 31) / 32) * ((H + 3) / 4); }
 void launch_conv(const ConvArgs& a, hipStream_t stream);
+// wave-specialised persistent variant (conv_ws.hip); launch_conv forwards to it when CDDPM_CONV_WS=1 is set
+void launch_conv_ws(const ConvArgs& a, hipStream_t stream);
 
 // packed weight image sizes / packing (host side, cddpm_api.hip)
 // layout: [Cout/128][Cin/32][taps][128 rows x 8 slots of float4], slot s of row j stored at s ^ ((j>>1)&7)

@@ -44,7 +44,11 @@ def child(B, iters):
         flops = 2.0 * B * H * W * Cout * ((C0 + C1) * k * k + sk)
         row = {"shape": name, "ms": ms.value, "tflops": flops / ms.value / 1e9}
         tot = [sum(st[w * 8 + i] for w in range(4)) for i in range(6)]
-        if sum(tot):
+        if st[41]:
+            row["clock_GHz"] = round(st[40] / st[41] * 0.1, 3)
+        if os.environ.get("CDDPM_CONV_WS") == "1" and sum(st[:4]):
+            row["ws_cycles"] = {"matrix work": int(st[0]), "matrix barrier": int(st[1]), "staging work": int(st[2]), "staging barrier": int(st[3])}
+        elif sum(tot):
             row["phase_share"] = {p: round(t / sum(tot), 4) for p, t in zip(PHASES, tot)}
         out.append(row)
     print(json.dumps(out))
@@ -65,7 +69,12 @@ def main():
         res = {}
         for r in range(rounds):          # interleaved rounds
             for tag in sys.argv[2:]:
-                env = dict(os.environ, CDDPM_LIB=os.path.join(CSRC, f"libcddpm_hip_{tag}.so"))
+                lib, _, opt = tag.partition("+")          # "cur+ws": library cur with CDDPM_CONV_WS=1
+                env = dict(os.environ, CDDPM_LIB=os.path.join(CSRC, f"libcddpm_hip_{lib}.so"))
+                if opt == "ws":
+                    env["CDDPM_CONV_WS"] = "1"
+                if opt in ("w4", "w8"):
+                    env["CDDPM_CONV_WAVES"] = opt[1]
                 o = subprocess.run([sys.executable, __file__, "--child", str(B), "5"], env=env, capture_output=True, text=True)
                 if o.returncode != 0:
                     print(tag, "FAILED", o.stderr[-2000:])
@@ -79,6 +88,10 @@ def main():
                 line = f"   {tag:10s} ms min {min(ms):8.3f} med {sorted(ms)[len(ms) // 2]:8.3f}  TF max {max(tf):6.1f}"
                 if "phase_share" in runs[0][i]:
                     line += "  " + json.dumps(runs[0][i]["phase_share"])
+                if "clock_GHz" in runs[0][i]:
+                    line += f"  clock {runs[0][i]['clock_GHz']} GHz"
+                if "ws_cycles" in runs[0][i]:
+                    line += "  " + json.dumps(runs[0][i]["ws_cycles"])
                 print(line)
 
 
