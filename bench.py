@@ -75,6 +75,12 @@ def main():
     ap.add_argument("--no-profile", action="store_true", help="no per-kernel HIP events in the timed steps")
     args = ap.parse_args()
 
+    # stdout carries exactly ONE line (the JSON result): anything libraries print there (RCCL's version banner,
+    # MIOpen/HIP notices) is sent to stderr for the duration of the run
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -180,7 +186,8 @@ def main():
         out["config"]["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
     eng.close()
     if rank == 0:
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.destroy_process_group()
 

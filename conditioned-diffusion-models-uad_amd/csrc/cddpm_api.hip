@@ -12,6 +12,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -994,6 +995,7 @@ int cddpm_op_conv_bench(cddpm_handle h, int C0, int C1, int Cout, int ksize, int
         if (!n) return 0;
         const size_t n4 = (n + 3) / 4 * 4;
         if (hipMalloc((void**)p, n4 * sizeof(float)) != hipSuccess) return -1;
+        if (getenv("CDDPM_BENCH_ZERO")) { (void)hipMemsetAsync(*p, 0, n4 * sizeof(float), s); return 0; }   // DVFS check: zeros vs random
         launch_noise_fill(*p, 1234, stream_id, 0, 0, 1, (int)n4, s);
         (void)scale;
         return 0;

@@ -47,17 +47,24 @@ __device__ __forceinline__ float silu_f(float v) {
     return v * __builtin_amdgcn_rcpf(1.0f + e);
 }
 
-template <int TAPS>
-__global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
+// NWV = waves per workgroup: 4 -> each wave owns 64 pixels x 64 couts (2 x 2 MFMA tiles), 2 workgroups per CU;
+//                            8 -> each wave owns 64 pixels x 32 couts (2 x 1 MFMA tiles), 2 workgroups per CU = 4 waves
+//                                 per SIMD: with four MFMA streams per SIMD the matrix pipe stays fed while some
+//                                 waves stage, wait at the per-tap barrier or run their epilogue.
+template <int TAPS, int NWV>
+__global__ __launch_bounds__(64 * NWV, NWV / 2) void conv_mfma_kernel(const ConvArgs a) {
+    constexpr int THREADS = 64 * NWV;
+    constexpr int NT = 8 / NWV;                 // 32-cout MFMA tiles per wave: 2 | 1
     constexpr int PAD = (TAPS == 9) ? 1 : 0;
     constexpr int PW = 32 + 2 * PAD;            // patch width  (pixels)
     constexpr int PH = 4 + 2 * PAD;             // patch height (pixels)
     constexpr int NPIX = PW * PH;               // 204 | 128
-    constexpr int NK = (NPIX * 8 + 255) / 256;  // v4f patch entries per thread: 7 | 4
+    constexpr int NK = (NPIX * 8 + THREADS - 1) / THREADS;  // v4f patch entries per thread: 7 | 4 (4 waves), 4 | 2 (8 waves)
+    constexpr int WK = 1024 / THREADS;          // v4f of a weight slab per thread: 4 | 2
 
     extern __shared__ v4f lds[];
     v4f* ldsA = lds;                // NPIX * 8 v4f
-    v4f* ldsW = lds + NPIX * 8;     // 2 * 1024 v4f
+    v4f* ldsW = lds + NPIX * 8;     // 3 * 1024 v4f (ring of weight slabs)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -65,11 +72,12 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
 #ifdef CDDPM_STAMPS
     unsigned long long st_[6] = {0, 0, 0, 0, 0, 0};
     unsigned long long last_ = __builtin_amdgcn_s_memtime();
+    const unsigned long long t0c_ = last_, t0r_ = __builtin_amdgcn_s_memrealtime();   // in-kernel clock = dc / dr * 100 MHz
 #endif
     const int li = lane & 31;
     const int lh = lane >> 5;
     const int wm = wave & 1;    // pixel rows {0,1} | {2,3}
-    const int wn = wave >> 1;   // cout 0..63 | 64..127
+    const int wn = wave >> 1;   // cout block of 32 * NT within the 128
 
     const int ncb = a.Cout >> 7;
     const int tilesX = (a.W + 31) >> 5;
@@ -88,38 +96,31 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
     const int nch_skip = (a.S0 + a.S1) >> 5;
     const int nch = nch_main + nch_skip;
 
-    // ---- per-thread patch entries: slot s is fixed per thread, pixel q = (tid>>3) + 32k
+    // ---- per-thread patch entries: slot s is fixed per thread, pixel q = (tid>>3) + (THREADS/8) k
     const int s = tid & 7;
-    int psrc[NK];    // source pixel index (main segment), -1 = zero padding / outside
-    int pskip[NK];   // source pixel index (skip segment, output resolution, centre pixels only)
-    int ldsoff[NK];
+    int psrc[NK];           // source pixel index (main segment), -1 = zero padding / outside
+    unsigned centre = 0;    // bit k: entry k is a centre (non-halo) pixel inside the image -> read by the skip segment,
+                            // whose sources live at the output resolution (same index: such convs never upsample)
 #pragma unroll
     for (int k = 0; k < NK; ++k) {
-        const int q = (tid >> 3) + 32 * k;
+        const int q = (tid >> 3) + (THREADS / 8) * k;
         const int pr = q / PW, pc = q - pr * PW;
         const int y = y0 + pr - PAD, x = x0 + pc - PAD;
         const bool valid = (q < NPIX) && (y >= 0) && (y < a.H) && (x >= 0) && (x < a.W);
         const int sy = a.upsample ? (y >> 1) : y, sx = a.upsample ? (x >> 1) : x;
         psrc[k] = valid ? ((b * a.srcH + sy) * a.srcW + sx) : -1;
-        const bool centre = valid && (pr >= PAD) && (pr < PH - PAD) && (pc >= PAD) && (pc < PW - PAD);
-        pskip[k] = centre ? ((b * a.H + y) * a.W + x) : -1;
-        ldsoff[k] = (q < NPIX) ? (q * 8 + (s ^ ((q >> 1) & 7))) : -1;
+        if (valid && (pr >= PAD) && (pr < PH - PAD) && (pc >= PAD) && (pc < PW - PAD)) centre |= 1u << k;
     }
 
     const v4f* wmain = reinterpret_cast<const v4f*>(a.wpk) + (size_t)cb * nch_main * TAPS * 1024;
     const v4f* wskip = reinterpret_cast<const v4f*>(a.skip_wpk) + (size_t)cb * nch_skip * 1024;
 
-    v4f wreg[4];
+    v4f wreg[WK];
     v4f areg[NK];
-    v4f cm, ca, cd;   // coefficients of this thread's 4 channels for the chunk held in areg
-    bool have_coef = false;
+    // GroupNorm/FiLM coefficients of this sample (3 x Cin floats), cached in LDS by the prologue
+    v4f* ldsC = lds + NPIX * 8 + 3072;
+    const bool have_coef = (a.coef != nullptr);
 
-    // stage pointer: slab of (chunk, tap); past the end it wraps to stage 0 so the prefetch stays unconditional
-    auto wslab = [&](int chunk, int tap) -> const v4f* {
-        if (chunk >= nch) { chunk = 0; tap = 0; }
-        return (chunk < nch_main) ? (wmain + ((size_t)chunk * TAPS + tap) * 1024)
-                                  : (wskip + (size_t)(chunk - nch_main) * 1024);
-    };
     auto load_act = [&](int chunk) {
         const float* base;
         int Cs, c0;
@@ -128,23 +129,14 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
             const int ch = chunk << 5;
             if (ch < a.C0) { base = a.src0; Cs = a.C0; c0 = ch; }
             else           { base = a.src1; Cs = a.C1; c0 = ch - a.C0; }
-            have_coef = (a.coef != nullptr);
-            if (have_coef) {
-                const size_t ci = (size_t)b * Cin + ch + 4 * s;
-                const size_t plane = (size_t)a.B * Cin;
-                cm = *reinterpret_cast<const v4f*>(a.coef + ci);
-                ca = *reinterpret_cast<const v4f*>(a.coef + plane + ci);
-                cd = *reinterpret_cast<const v4f*>(a.coef + 2 * plane + ci);
-            }
         } else {
             const int ch = (chunk - nch_main) << 5;
             if (ch < a.S0) { base = a.skip0; Cs = a.S0; c0 = ch; }
             else           { base = a.skip1; Cs = a.S1; c0 = ch - a.S0; }
-            have_coef = false;
         }
 #pragma unroll
         for (int k = 0; k < NK; ++k) {
-            const int p = main_seg ? psrc[k] : pskip[k];
+            const int p = (main_seg || ((centre >> k) & 1u)) ? psrc[k] : -1;
             v4f v = v4f{0.f, 0.f, 0.f, 0.f};
             if (p >= 0) v = *reinterpret_cast<const v4f*>(base + (size_t)p * Cs + c0 + 4 * s);
             areg[k] = v;
@@ -153,20 +145,24 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
     auto store_act = [&](int chunk) {
         const bool main_seg = chunk < nch_main;
         const bool do_silu = main_seg && a.silu;
+        v4f cm = v4f{0.f, 0.f, 0.f, 0.f}, ca = v4f{1.f, 1.f, 1.f, 1.f}, cd = cm;
+        const bool aff = main_seg && have_coef;
+        if (aff) {
+            const int ci = (chunk << 3) + s;
+            cm = ldsC[ci];
+            ca = ldsC[(Cin >> 2) + ci];
+            cd = ldsC[2 * (Cin >> 2) + ci];
+        }
 #pragma unroll
         for (int k = 0; k < NK; ++k) {
             v4f v = areg[k];
-            const int p = main_seg ? psrc[k] : pskip[k];
+            const int p = (main_seg || ((centre >> k) & 1u)) ? psrc[k] : -1;
             if (p >= 0) {   // zero padding stays exactly zero: the conv pads AFTER the activation
-                if (have_coef) {
-                    v.x = (v.x - cm.x) * ca.x + cd.x;
-                    v.y = (v.y - cm.y) * ca.y + cd.y;
-                    v.z = (v.z - cm.z) * ca.z + cd.z;
-                    v.w = (v.w - cm.w) * ca.w + cd.w;
-                }
+                if (aff) v = (v - cm) * ca + cd;
                 if (do_silu) { v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w); }
             }
-            if (ldsoff[k] >= 0) ldsA[ldsoff[k]] = v;
+            const int q = (tid >> 3) + (THREADS / 8) * k;
+            if (q < NPIX) ldsA[q * 8 + (s ^ ((q >> 1) & 7))] = v;
         }
     };
 
@@ -174,95 +170,152 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
     // `tot` sums the chunks. A single K-long fp32 fmaf chain (K up to 4608 + 512) carries ~sqrt(K/2) ulp of
     // rounding noise, about 3x what the reference's blocked CPU convolution shows against fp64; splitting the
     // chain brings this kernel to the same level (measured in tests/test_gpu_unet.py, fp64 yardstick).
-    f32x16 acc[2][2], tot[2][2];
+    f32x16 acc[2][NT], tot[2][NT];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NT; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; tot[i][j][r] = 0.f; }
 
     // B operand (weights) LDS offsets: row j = cout within the 128 block
-    int boff[2], bsw[2];
+    int boff[NT], bsw[NT];
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-        const int j = 64 * wn + 32 * nt + li;
+    for (int nt = 0; nt < NT; ++nt) {
+        const int j = 32 * NT * wn + 32 * nt + li;
         boff[nt] = j * 8;
         bsw[nt] = (j >> 1) & 7;
     }
 
-    auto compute = [&](int tap, int buf) {
+    // ---- main loop.
+    //   weights: THREE LDS slots. During stage st (one tap x 32 channels = 16 NT MFMAs x 4 groups per wave) the slab of
+    //            stage st+2 goes registers -> LDS and the slab of stage st+3 global -> registers, both tucked between
+    //            MFMA groups; nothing a wave needs next is younger than one full stage, so the per-stage barrier
+    //            never waits on data and the next stage's first fragments are already in registers when it opens.
+    //   patch  : single buffer per 32-channel chunk; the next chunk's patch is fetched behind the last tap's MFMAs
+    //            and activated/stored between the two chunk-boundary barriers.
+    //   A/B fragments: two register sets, group g+1 is read while group g multiplies.
+    const int S_main = nch_main * TAPS, S_all = S_main + nch_skip;
+    auto wstage = [&](int n) -> const v4f* {     // packed image of stage n (clamped: the tail prefetch re-reads the last one)
+        n = n < S_all ? n : S_all - 1;
+        return n < S_main ? wmain + (size_t)n * 1024 : wskip + (size_t)(n - S_main) * 1024;
+    };
+    auto a_off = [&](int tap, int mt) -> int {   // v4f offset of this lane's pixel row for a tap; swizzle key in bits 28..30
         const int ky = (TAPS == 9) ? (tap / 3) : 0;
         const int kx = (TAPS == 9) ? (tap - 3 * ky) : 0;
-        int aoff[2], asw[2];
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            const int q = (2 * wm + mt + ky) * PW + li + kx;
-            aoff[mt] = q * 8;
-            asw[mt] = (q >> 1) & 7;
-        }
-        const v4f* wb = ldsW + buf * 1024;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int sl = 2 * g + lh;
-            const v4f a0 = ldsA[aoff[0] + (sl ^ asw[0])];
-            const v4f a1 = ldsA[aoff[1] + (sl ^ asw[1])];
-            const v4f b0 = wb[boff[0] + (sl ^ bsw[0])];
-            const v4f b1 = wb[boff[1] + (sl ^ bsw[1])];
-            const float av0[4] = {a0.x, a0.y, a0.z, a0.w};
-            const float av1[4] = {a1.x, a1.y, a1.z, a1.w};
-            const float bv0[4] = {b0.x, b0.y, b0.z, b0.w};
-            const float bv1[4] = {b1.x, b1.y, b1.z, b1.w};
-#pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[m], bv0[m], acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[m], bv1[m], acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[m], bv0[m], acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[m], bv1[m], acc[1][1], 0, 0, 0);
-            }
-        }
+        const int q = (2 * wm + mt + ky) * PW + li + kx;
+        return (q * 8) | (((q >> 1) & 7) << 28);
     };
+    v4f fa[2][2], fb[2][NT];                     // [set][mt] / [set][nt]
+#define CONV_READ(SET, O0, O1, WB, G)                                                            \
+    {                                                                                            \
+        const int sl_ = 2 * (G) + lh;                                                            \
+        fa[SET][0] = ldsA[((O0) & 0x0fffffff) + (sl_ ^ ((O0) >> 28))];                           \
+        fa[SET][1] = ldsA[((O1) & 0x0fffffff) + (sl_ ^ ((O1) >> 28))];                           \
+        _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) fb[SET][nt] = (WB)[boff[nt] + (sl_ ^ bsw[nt])]; \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+    }
+#define CONV_MFMA(SET)                                                                           \
+    {                                                                                            \
+        const float av0_[4] = {fa[SET][0].x, fa[SET][0].y, fa[SET][0].z, fa[SET][0].w};          \
+        const float av1_[4] = {fa[SET][1].x, fa[SET][1].y, fa[SET][1].z, fa[SET][1].w};          \
+        _Pragma("unroll") for (int m = 0; m < 4; ++m) {                                          \
+            _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) {                                  \
+                const float bv_ = (m == 0) ? fb[SET][nt].x : (m == 1) ? fb[SET][nt].y : (m == 2) ? fb[SET][nt].z : fb[SET][nt].w; \
+                acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0_[m], bv_, acc[0][nt], 0, 0, 0); \
+                acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1_[m], bv_, acc[1][nt], 0, 0, 0); \
+            }                                                                                    \
+        }                                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+    }
 
-    // ---- main loop: weights double-buffered in LDS and prefetched through registers one stage ahead;
-    //      the next chunk's patch is fetched into registers behind the last tap's MFMAs.
-    {
-        const v4f* p0 = wslab(0, 0);
+    // prologue: slabs of stages 0 and 1 straight to LDS, registers <- stage 2, patch of chunk 0, coefficient cache
+    for (int n = 0; n < 2; ++n) {
+        const v4f* p = wstage(n);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) wreg[i] = p0[tid + 256 * i];
+        for (int i = 0; i < WK; ++i) ldsW[n * 1024 + tid + THREADS * i] = p[tid + THREADS * i];
+    }
+    {
+        const v4f* p = wstage(2);
+#pragma unroll
+        for (int i = 0; i < WK; ++i) wreg[i] = p[tid + THREADS * i];
     }
     load_act(0);
-    int buf = 0;
+    if (have_coef) {
+        const int nq = Cin >> 2;
+        const size_t plane = (size_t)a.B * Cin;
+        for (int i = tid; i < 3 * nq; i += THREADS) {
+            const int pl = i / nq, c4 = i - pl * nq;
+            ldsC[i] = *reinterpret_cast<const v4f*>(a.coef + pl * plane + (size_t)b * Cin + 4 * c4);
+        }
+    }
+    __syncthreads();
+    store_act(0);
+    __syncthreads();
     STAMP(0)
+    int st = 0;
     for (int chunk = 0; chunk < nch; ++chunk) {
         const bool main_seg = chunk < nch_main;
         const int ntap = main_seg ? TAPS : 1;
-        __syncthreads();   // every wave is done reading the previous patch
-        store_act(chunk);
-        STAMP(1)
-        for (int t = 0; t < ntap; ++t) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) ldsW[buf * 1024 + tid + 256 * i] = wreg[i];
+        {
+            const int t0 = main_seg ? 0 : (TAPS / 2);        // single-tap (skip) segment: centre tap
+            const int o0 = a_off(t0, 0), o1 = a_off(t0, 1);
+            const v4f* wb = ldsW + (st % 3) * 1024;
+            CONV_READ(0, o0, o1, wb, 0)
+        }
+        for (int t = 0; t < ntap; ++t, ++st) {
+            const int tap = main_seg ? t : (TAPS / 2);
             const bool last_tap = (t == ntap - 1);
-            const v4f* pn = last_tap ? wslab(chunk + 1, 0) : wslab(chunk, t + 1);
+            const int o0 = a_off(tap, 0), o1 = a_off(tap, 1);
+            const v4f* wb = ldsW + (st % 3) * 1024;
+            CONV_READ(1, o0, o1, wb, 1)
+            CONV_MFMA(0)
+            if (st + 2 < S_all) {                             // slab of stage st+2: registers -> LDS
+                v4f* wd = ldsW + ((st + 2) % 3) * 1024;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) wreg[i] = pn[tid + 256 * i];
-            if (last_tap && chunk + 1 < nch) load_act(chunk + 1);
-            __syncthreads();
-            STAMP(2)
-            compute(main_seg ? t : (TAPS / 2), buf);   // skip segment: centre tap
-            buf ^= 1;
+                for (int i = 0; i < WK; ++i) wd[tid + THREADS * i] = wreg[i];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            CONV_READ(0, o0, o1, wb, 2)
+            CONV_MFMA(1)
+            {                                                 // slab of stage st+3: global -> registers
+                const v4f* pn = wstage(st + 3);
+#pragma unroll
+                for (int i = 0; i < WK; ++i) wreg[i] = pn[tid + THREADS * i];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            CONV_READ(1, o0, o1, wb, 3)
+            CONV_MFMA(0)
+            if (last_tap) {
+                if (chunk + 1 < nch) load_act(chunk + 1);     // lands behind the last 16 NT MFMAs
+                __builtin_amdgcn_sched_barrier(0);
+            } else {                                          // group 0 of the next tap: same patch, next slot
+                const int n0 = a_off(tap + 1, 0), n1 = a_off(tap + 1, 1);
+                const v4f* wbn = ldsW + ((st + 1) % 3) * 1024;
+                CONV_READ(0, n0, n1, wbn, 0)
+            }
+            CONV_MFMA(1)
             STAMP(3)
+            __syncthreads();   // stage st done everywhere: its slot may be refilled, the slab written above is visible
+            STAMP(2)
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
+            for (int j = 0; j < NT; ++j) {
                 tot[i][j] += acc[i][j];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
             }
         STAMP(4)
+        if (chunk + 1 < nch) {
+            store_act(chunk + 1);   // every wave passed the stage barrier: the old patch is dead
+            __syncthreads();
+        }
+        STAMP(1)
     }
+#undef CONV_READ
+#undef CONV_MFMA
 
     __syncthreads();   // every wave is done with the patch / weight buffers before they become transpose space
     // ---- epilogue. The accumulator layout (D row = pixel (r&3) + 8 (r>>2) + 4 lh, D col = cout li) would give
@@ -275,8 +328,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
         const int cq = lane & 7;                                      // channel quad of this lane in the read phase
         const int prow = lane >> 3;                                   // pixel row within a group of 8
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-            const int co = cb * 128 + 64 * wn + 32 * nt + 4 * cq;
+        for (int nt = 0; nt < NT; ++nt) {
+            const int co = cb * 128 + 32 * NT * wn + 32 * nt + 4 * cq;
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -336,22 +389,42 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
     }
 #ifdef CDDPM_STAMPS
     STAMP(5)
-    if (a.stamps && lane == 0)
+    if (a.stamps && lane == 0) {
         for (int i = 0; i < 6; ++i) atomicAdd(&a.stamps[wave * 8 + i], st_[i]);
+        if (wave == 0) {
+            atomicAdd(&a.stamps[40], __builtin_amdgcn_s_memtime() - t0c_);
+            atomicAdd(&a.stamps[41], __builtin_amdgcn_s_memrealtime() - t0r_);
+        }
+    }
 #endif
 }
 
 void launch_conv(const ConvArgs& a, hipStream_t stream) {
     static const bool use_ws = [] { const char* e = getenv("CDDPM_CONV_WS"); return e && e[0] == '1'; }();
     if (use_ws) { launch_conv_ws(a, stream); return; }
+    // 4 waves (64 x 64 per wave, 2 waves per SIMD) is the default; CDDPM_CONV_WAVES=8 selects the 8-wave split
+    // (64 x 32 per wave, 4 waves per SIMD), which measures the same throughput (tools/conv_ab.py, profiles/)
+    static const int nwv = [] { const char* e = getenv("CDDPM_CONV_WAVES"); return (e && e[0] == '8') ? 8 : 4; }();
     const int tilesX = (a.W + 31) / 32, tilesY = (a.H + 3) / 4;
     const unsigned grid = (unsigned)(a.B * tilesX * tilesY * (a.Cout / 128));
-    if (a.taps == 9) {
-        const size_t lds = (size_t)(6 * 34 * 8 + 2048) * 16;
-        hipLaunchKernelGGL(conv_mfma_kernel<9>, dim3(grid), dim3(256), lds, stream, a);
+    // patch + 2 weight slabs; the epilogue reuses the space as NWV private 8-KB transpose regions
+    const size_t coef_lds = a.coef ? (size_t)3 * (a.C0 + a.C1) * sizeof(float) : 0;
+    const size_t need9 = (size_t)(6 * 34 * 8 + 3072) * 16 + coef_lds, need1 = (size_t)(4 * 32 * 8 + 3072) * 16 + coef_lds;
+    if (nwv == 8) {
+        const size_t tr = 8 * 2048 * sizeof(float);
+        static bool attr = false;
+        if (!attr) {   // > 64 KB of dynamic LDS needs the opt-in; 80 KB still leaves two workgroups per CU
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_mfma_kernel<9, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 82 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_mfma_kernel<1, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 82 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_mfma_kernel<9, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 82 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_mfma_kernel<1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 82 * 1024);
+            attr = true;
+        }
+        if (a.taps == 9) hipLaunchKernelGGL((conv_mfma_kernel<9, 8>), dim3(grid), dim3(512), need9 > tr ? need9 : tr, stream, a);
+        else hipLaunchKernelGGL((conv_mfma_kernel<1, 8>), dim3(grid), dim3(512), need1 > tr ? need1 : tr, stream, a);
     } else {
-        const size_t lds = (size_t)(4 * 32 * 8 + 2048) * 16;
-        hipLaunchKernelGGL(conv_mfma_kernel<1>, dim3(grid), dim3(256), lds, stream, a);
+        if (a.taps == 9) hipLaunchKernelGGL((conv_mfma_kernel<9, 4>), dim3(grid), dim3(256), need9, stream, a);
+        else hipLaunchKernelGGL((conv_mfma_kernel<1, 4>), dim3(grid), dim3(256), need1, stream, a);
     }
 }
 
