@@ -11,7 +11,7 @@ import sys
 from concurrent.futures import ThreadPoolExecutor
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-SOURCES = ["conv_mfma.hip", "conv_ws.hip", "norm_kernels.hip", "small_kernels.hip", "attention.hip", "cddpm_api.hip"]
+SOURCES = ["conv_mfma.hip", "conv_ws.hip", "norm_kernels.hip", "small_kernels.hip", "attention.hip", "simplex.hip", "cddpm_api.hip"]
 LIB = os.path.join(CSRC, "libcddpm_hip.so")
 ARCH = "gfx950"
 
@@ -53,7 +53,7 @@ def build_lib(force: bool = False, verbose: bool = False, defines=(), tag: str =
             print(r.stderr, file=sys.stderr)
         return obj
 
-    with ThreadPoolExecutor(max_workers=min(6, os.cpu_count() or 1)) as ex:
+    with ThreadPoolExecutor(max_workers=min(7, os.cpu_count() or 1)) as ex:
         objs = list(ex.map(compile_one, SOURCES))
     r = subprocess.run([hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", lib_out, *objs], capture_output=True, text=True)
     if r.returncode != 0:

@@ -15,8 +15,9 @@ Differences, on purpose:
   * no CPU path: tensors must live on the MI355X, otherwise a RuntimeError (never a silent fallback);
   * `use_spatial_transformer` is set to False here -- the reference reads it in model_predictions (:401) but
     never assigns it, so its own p_sample crashes; this is the intended semantics (experiment yaml :31);
-  * Gaussian branch only: the simplex branch (`noise is not None`: gen_noise redrawn every step on the CPU,
-    :441-443, :450-452) and `box` in-painting are outside the accelerated path and raise NotImplementedError;
+  * the simplex branch (`noise is not None`, :441-443, :450-452) draws its fields on the device (csrc/simplex.hip,
+    bit-exact with the reference's CPU generator for a given seed) instead of numba + host->device copies per step;
+    `box` in-painting is outside the accelerated path and raises NotImplementedError;
   * noise: x_T and z_t come from the counter RNG (synth.py / on-device Philox) seeded from torch's global
     generator, so `torch.manual_seed` still makes runs reproducible; pass `seed=`/`slice0=` to pin them.
 """
@@ -29,6 +30,7 @@ import torch.nn as nn
 
 from . import schedule as _schedule
 from . import synth as _synth
+from .generate_noise import gen_noise
 
 ModelPrediction = namedtuple("ModelPrediction", ["pred_noise", "pred_x_start"])
 
@@ -126,12 +128,13 @@ class GaussianDiffusion(nn.Module):
     @torch.no_grad()
     def p_sample(self, x, t: int, clip_denoised=True, cond=None, cond_scale=1., noise=None, *, z=None, seed=None, slice0=0):
         """x_t -> x_{t-1} (cond_DDPM.py:432-444). `z`: this step's N(0,1) draw (else drawn on the device)."""
-        if noise is not None:
-            raise NotImplementedError("simplex-noise branch (gen_noise each step, cond_DDPM.py:441-443) is not accelerated")
         if not clip_denoised:
             raise NotImplementedError("clip_denoised=False is not part of the reconstruction path")
         B, _c, H, W = x.shape
         eng = self._engine(B, H, W, x.device)
+        if noise is not None:
+            # reference :441-443: the passed tensor only selects the branch; a NEW simplex field is drawn for the step
+            z = gen_noise(self.cfg, x.shape, engine=eng).float() if t > 0 else None
         return eng.p_sample(x.float(), int(t), cond.float() if cond is not None else None, z=z, seed=self._draw_seed(seed), slice0=slice0)
 
     @torch.no_grad()
@@ -140,15 +143,30 @@ class GaussianDiffusion(nn.Module):
         """Full reverse loop (cond_DDPM.py:446-464): T = num_timesteps if start_t == 0 else start_t, x_T ~ N(0,1),
         T steps, result mapped to [0,1]. Extras: x_T / z_noise ([T,B,1,H,W], z_t at index t) inject given draws,
         seed / slice0 key the counter RNG (slice0 = global index of the first slice, for sharded runs)."""
-        if noise is not None:
-            raise NotImplementedError("simplex-noise branch (q_sample start + gen_noise per step, cond_DDPM.py:450-452) "
-                                      "is not accelerated; call with noise=None")
         if box is not None:
             raise NotImplementedError("box in-painting is not part of the cDDPM reconstruction path")
         B, _c, H, W = shape
         dev = torch.device(device) if device is not None else (cond.device if cond is not None else self.betas.device)
         T = self.num_timesteps if start_t == 0 else int(start_t)
         eng = self._engine(B, H, W, dev)
+        if noise is not None:
+            # Simplex branch (:450-452, :441-443): start from q_sample(x_start, t=T, simplex field), then one fresh
+            # simplex field per step (the same field for every batch item). T indexes the schedule directly, so
+            # start_t must be in [1, num_timesteps - 1] (start_t == 0 reads index num_timesteps in the reference: an
+            # out-of-range access there, an error here). Fields come from csrc/simplex.hip, seeds from numpy's RNG.
+            if x_start is None:
+                raise ValueError("the simplex branch of p_sample_loop needs x_start")
+            if not (1 <= T < self.num_timesteps):
+                raise ValueError(f"simplex branch: start_t must be in [1, {self.num_timesteps - 1}], got {start_t}")
+            field = gen_noise(self.cfg, (B, _c, H, W), engine=eng).float()
+            tT = torch.full((B,), T, device=dev, dtype=torch.long)
+            img = (_extract(self.sqrt_alphas_cumprod, tT, x_start.shape) * x_start.float()
+                   + _extract(self.sqrt_one_minus_alphas_cumprod, tT, x_start.shape) * field)[:, 0].unsqueeze(1).contiguous()
+            eng.prepare_cond(cond.float() if cond is not None else None, B)
+            for t in reversed(range(0, T)):
+                z = gen_noise(self.cfg, (B, 1, H, W), engine=eng).float() if t > 0 else None
+                img = eng.p_sample(img, t, None, z=z)
+            return unnormalize_to_zero_to_one(img)
         seed = self._draw_seed(seed)
         if x_T is None:
             x_T = eng.noise_fill(B, H, W, seed=seed, stream_id=_synth.STREAM_XT, slice0=slice0)

@@ -905,6 +905,19 @@ int cddpm_noise_fill(cddpm_handle h, float* out_dev, uint64_t seed, uint32_t str
     return 0;
 }
 
+int cddpm_simplex_fill(cddpm_handle h, uint16_t* out_f16_dev, int64_t seed, int B, int H, int W, int octaves,
+                       double persistence, double frequency, void* stream) {
+    if (!h) return -1;
+    if (!out_f16_dev || B < 1 || H < 1 || W < 1 || octaves < 1 || !(frequency > 0))
+        return fail(h, "bad arguments to cddpm_simplex_fill");
+    if (H != W)
+        return fail(h, "simplex noise is defined for square fields only (the reference's _noise2a index assumes H == W), got %dx%d", H, W);
+    HIPCHECK(h, hipSetDevice(h->device));
+    launch_simplex(out_f16_dev, (long long)seed, B, H, W, octaves, persistence, frequency, (hipStream_t)stream);
+    HIPCHECK(h, hipGetLastError());
+    return 0;
+}
+
 int cddpm_q_sample(cddpm_handle h, const float* x01_dev, const float* noise_dev, const int32_t* t_dev, int t_uniform,
                    const float* sqrt_ac_host, const float* sqrt_1mac_host, int T, float* out_dev, int B, int H, int W,
                    void* stream) {

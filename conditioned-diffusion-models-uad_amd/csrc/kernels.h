@@ -92,6 +92,10 @@ void launch_noise_fill(float* out, uint64_t seed, uint32_t stream_id, int t, uin
 void launch_q_sample(const float* x01, const float* noise, const int* t_dev, const float* sa, const float* s1ma,
                      float* out, int B, int HW, hipStream_t stream);
 
+// 2-D OpenSimplex fractal noise, fp16 bits, the same field for every batch item (simplex.hip)
+void launch_simplex(unsigned short* out, long long seed, int B, int H, int W, int octaves, double persistence,
+                    double frequency, hipStream_t stream);
+
 // ------------------------------------------------------------------------------------------------
 // attention core (attention.hip): qkv NHWC [B,N,3C] -> out [B,N,C], heads of 64 channels
 // ------------------------------------------------------------------------------------------------

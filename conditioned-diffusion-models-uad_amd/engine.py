@@ -212,6 +212,15 @@ class CddpmEngine:
                                            _stream_ptr(self.device)), "cddpm_noise_fill")
         return out
 
+    def simplex_noise(self, B: int, H: int, W: int, *, seed: int, octaves: int = 6, persistence: float = 0.8,
+                      frequency: float = 64.0) -> torch.Tensor:
+        """gen_noise for noisetype 'simplex': float16 [B,1,H,W], the same field for every batch item, bit-exact
+        with the reference's CPU generator for the given newSeed value."""
+        out = torch.empty((B, 1, H, W), dtype=torch.float16, device=self.device)
+        self._ck(self.lib.cddpm_simplex_fill(self._h, out.data_ptr(), int(seed), B, H, W, octaves, float(persistence),
+                                             float(frequency), _stream_ptr(self.device)), "cddpm_simplex_fill")
+        return out
+
     def q_sample(self, x01: torch.Tensor, t, noise: torch.Tensor) -> torch.Tensor:
         x01 = _check_dev(x01, "x01", self.device)
         noise = _check_dev(noise, "noise", self.device)

@@ -113,6 +113,14 @@ int cddpm_p_sample(cddpm_handle h, float* img_inout_dev, const float* z_dev, uin
 int cddpm_noise_fill(cddpm_handle h, float* out_dev, uint64_t seed, uint32_t stream_id, int t,
                      uint64_t slice0, int B, int H, int W, void* stream);
 
+/* Replaces gen_noise(cfg, shape) for noisetype 'simplex' (src/utils/generate_noise.py:8-52: Simplex_CLASS, _init :214-232,
+ * rand_2d_octaves :97-114, _noise2 :252-352; numba CPU code + H2D copy on every step in the reference). out_f16_dev
+ * receives [B,1,H,W] IEEE half bit patterns: the SAME field for every batch item, float64 arithmetic rounded to float16
+ * as torch's .half() does -- bit-exact with the reference for a given `seed` (the value Simplex_CLASS.newSeed draws with
+ * np.random.randint). Square fields only, like the reference. Reference parameters: octaves 6, persistence 0.8, frequency 64. */
+int cddpm_simplex_fill(cddpm_handle h, uint16_t* out_f16_dev, int64_t seed, int B, int H, int W, int octaves,
+                       double persistence, double frequency, void* stream);
+
 /* Replaces q_sample (src/models/modules/cond_DDPM.py:548-554) fused with normalize_to_neg_one_to_one (:75):
  * out = sqrt_ac[t_b] * (2 x01 - 1) + sqrt_1mac[t_b] * noise; coefficient tables are host arrays [T]
  * uploaded on first use. Used by the single-step reconstruction (GaussianDiffusion.forward, :647-655). */

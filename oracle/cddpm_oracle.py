@@ -291,3 +291,22 @@ def to_float64(d: Dict[str, Tensor]) -> Dict[str, Tensor]:
     """float64 copies of a state_dict / buffer dict: the same restatement then runs without fp32 rounding
     (yardstick for how far two fp32 implementations may legitimately differ)."""
     return {k: v.double() for k, v in d.items()}
+
+
+def p_sample_loop_simplex(x_start: Tensor, cond: Optional[Tensor], sd, buf, seeds: Sequence[int], start_t: int,
+                          objective: str = "pred_x0", **unet_kw) -> Tensor:
+    """p_sample_loop, simplex branch (`noise is not None`; cond_DDPM.py:449-452, :441-443, :460-463):
+    img = q_sample(x_start, t=[T], gen_noise())[:, 0:1]; each step t = T-1 .. 0 draws a NEW simplex field with
+    gen_noise (float16 -> float32, the same field for every batch item; nothing added at t = 0); (img + 1) / 2.
+    `seeds[0]` seeds the start field, `seeds[1 + k]` the field of the k-th step (t = T-1-k), i.e. the values
+    Simplex_CLASS.newSeed would draw. T = start_t must index the schedule (1 <= T < num_timesteps)."""
+    import simplex_oracle as SX
+    T = int(start_t)
+    B, C, H, W = x_start.shape
+    field = torch.from_numpy(SX.gen_noise(seeds[0], (B, C, H, W))).float()
+    img = (buf["sqrt_alphas_cumprod"][T] * x_start + buf["sqrt_one_minus_alphas_cumprod"][T] * field)[:, 0].unsqueeze(1)
+    with torch.no_grad():
+        for k, t in enumerate(reversed(range(T))):
+            z = torch.from_numpy(SX.gen_noise(seeds[1 + k], (B, 1, H, W))).float() if t > 0 else None
+            img = p_sample(img, t, cond, sd, buf, z, objective, **unet_kw)
+    return (img + 1) * 0.5

@@ -95,7 +95,7 @@ def test_diffusion_mirror_buffers_and_errors(oracle):
     with pytest.raises(RuntimeError):
         d.p_sample_loop((1, 1, 32, 32), cond=torch.zeros(1, 128))                # CPU tensors: loud, no fallback
     with pytest.raises(NotImplementedError):
-        d.p_sample_loop((1, 1, 32, 32), cond=torch.zeros(1, 128), noise=torch.zeros(1))   # simplex branch
+        d.p_sample_loop((1, 1, 32, 32), cond=torch.zeros(1, 128), box=torch.zeros(1, 4))   # box in-painting: out of scope
     with pytest.raises(AssertionError):
         D.GaussianDiffusion(m, image_size=32, objective="pred_v")
     with pytest.raises(ValueError):
