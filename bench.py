@@ -35,7 +35,10 @@ PKG = "conditioned-diffusion-models-uad_amd"
 T_TOTAL = 1000
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense fp32 MFMA peak (= fp32 vector peak)
 PEAK_HBM_TBPS = 8.0
-FLOP_PER_SLICE_STEP = {128: 265.6e9, 96: 149.1e9, 256: 1075.1e9}
+FLOP_PER_SLICE_STEP = {128: 265.6e9, 96: 149.1e9, 256: 1075.1e9}     # the reference's operation count
+# executed by this implementation: the two "nearest x2 upsample -> conv3x3" layers (4.83 + 19.33 GMAC @128^2) run as four
+# 2x2-tap convolutions of the low-resolution input = 4/9 of their multiplies
+EXECUTED_FRACTION = 1.0 - (4.832 + 19.328) * (5.0 / 9.0) / 132.79
 BYTES_PER_SLICE_STEP_128 = 1.043e9                                    # SURVEY.md 8(d), fused-kernel model
 
 
@@ -158,6 +161,8 @@ def main():
                    "gather_ms": gather_ms, "finite": finite,
                    "whole_step_tflops": flop_step / s_per_step / 1e12,
                    "whole_step_frac_of_fp32_peak": flop_step / s_per_step / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                   "whole_step_flops_note": "reference operation count (SURVEY 8d); executed count is x%.4f (folded upsample convs)" % EXECUTED_FRACTION,
+                   "executed_tflops": flop_step * EXECUTED_FRACTION / s_per_step / 1e12,
                    "hbm_frac_fused_model": (BYTES_PER_SLICE_STEP_128 * (S / 128.0) ** 2 * B + 0.1755e9) / s_per_step / (PEAK_HBM_TBPS * 1e12)},
     }
     if prof is not None:

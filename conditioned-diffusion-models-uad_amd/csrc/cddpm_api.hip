@@ -31,6 +31,7 @@ struct ResW {
     bool up = false, down = false, has_skip = false;
     NormW gn1, gn2;
     ConvW conv1, conv2, skip;
+    float* conv1_up2 = nullptr;   // up blocks: conv1 folded with the nearest x2 upsample (4 parity classes x 2x2 taps)
     float* bias2 = nullptr;   // conv2 bias (+ skip_connection bias when has_skip)
     int eoff = 0;             // offset of this block's (scale | shift) slice in the sumE-wide tables
 };
@@ -160,10 +161,10 @@ void conv_launch(cddpm_ctx* h, ConvArgs a, hipStream_t s) {
     auto it = h->stat_buf.find(a.out);       // outputs that can feed a GroupNorm get their statistics for free
     a.stats = (it != h->stat_buf.end()) ? it->second : nullptr;
     {
-        Prof p(h, a.taps == 9 ? PC_CONV3 : PC_CONV1, conv_flops(a), conv_bytes(a), s);
+        Prof p(h, a.taps == 1 ? PC_CONV1 : PC_CONV3, conv_flops(a), conv_bytes(a), s);   // taps 4 = folded upsample + 3x3
         launch_conv(a, s);
     }
-    if (a.stats) h->stat_n[a.out] = conv_stat_records(a.H, a.W);
+    if (a.stats) h->stat_n[a.out] = (a.taps == 4) ? conv_stat_records_up2(a.H, a.W) : conv_stat_records(a.H, a.W);
 }
 
 #define HIPCHECK(h, call)                                                                      \
@@ -390,7 +391,9 @@ size_t plan_workspace(cddpm_ctx* h, bool do_alloc, int* rc) {
         // statistics records: [B][records][C][2] fp32 per buffer that can feed a GroupNorm
         auto nrec_at = [&](int ds) {
             const int hh = d.max_h / ds, ww = d.max_w / ds;
-            return std::max(conv_stat_records(hh, ww), gn_nsplit(1, hh * ww));
+            // a tensor may be produced by the plain conv, the folded-upsample conv (more, smaller tiles on small
+            // images) or swept by gn_partial: size for the largest record count
+            return std::max(std::max(conv_stat_records(hh, ww), conv_stat_records_up2(hh, ww)), gn_nsplit(1, hh * ww));
         };
         size_t pi = 0;
         for (const Op& op : h->prog)
@@ -504,7 +507,8 @@ void run_res(cddpm_ctx* h, const ResW& r, const float* x0, int C0, const float* 
         resid = h->bufP1;
     } else if (r.up) {
         Ho = 2 * H; Wo = 2 * W;
-        a.src0 = x0; a.C0 = C0; a.srcH = H; a.srcW = W; a.upsample = 1; a.coef = h->coef; a.silu = 1;
+        a.src0 = x0; a.C0 = C0; a.srcH = H; a.srcW = W; a.coef = h->coef; a.silu = 1;
+        a.taps = 4; a.wpk = r.conv1_up2;      // folded upsample + conv
         res_up = 1;
     } else {
         a.src0 = x0; a.C0 = C0; a.src1 = x1; a.C1 = C1; a.srcH = H; a.srcW = W; a.coef = h->coef; a.silu = 1;
@@ -744,7 +748,15 @@ int cddpm_load_weights(cddpm_handle h, const char* const* names, const float* co
     std::vector<float> embw((size_t)h->sumE * h->E), embb(h->sumE);
     for (ResW& r : h->res) {
         if (upload_norm(h, hw, r.prefix + ".in_layers.0", r.Cin, &r.gn1)) return -1;
-        if (upload_conv(h, hw, r.prefix + ".in_layers.2", r.Cin, r.Cout, 9, &r.conv1)) return -1;
+        if (r.up) {
+            // the upsampled tensor is never built: Upsample(nearest x2) + Conv3x3 (OpenAI_Unet.py:118-128, :289-293) is
+            // evaluated as four 2x2-tap convolutions of the low-resolution input (4/9 of the multiplies)
+            r.conv1.Cin = r.Cin; r.conv1.Cout = r.Cout; r.conv1.taps = 4;
+            std::vector<float> pk((size_t)16 * r.Cout * r.Cin);
+            pack_conv_weights_up2(hw.get(r.prefix + ".in_layers.2.weight"), r.Cout, r.Cin, pk.data());
+            if (upload(h, &r.conv1_up2, pk.data(), pk.size())) return -1;
+            if (upload(h, &r.conv1.bias, hw.get(r.prefix + ".in_layers.2.bias"), r.Cout)) return -1;
+        } else if (upload_conv(h, hw, r.prefix + ".in_layers.2", r.Cin, r.Cout, 9, &r.conv1)) return -1;
         if (upload_norm(h, hw, r.prefix + ".out_layers.0", r.Cout, &r.gn2)) return -1;
         if (upload_conv(h, hw, r.prefix + ".out_layers.3", r.Cout, r.Cout, 9, &r.conv2, false)) return -1;
         std::vector<float> b2(hw.get(r.prefix + ".out_layers.3.bias"), hw.get(r.prefix + ".out_layers.3.bias") + r.Cout);
@@ -967,10 +979,13 @@ int cddpm_op_conv(cddpm_handle h, const float* src0, int C0, const float* src1, 
     if ((ksize != 1 && ksize != 3) || C0 % 32 || C1 % 32 || Cin <= 0 || Cout % 128 || Cout <= 0)
         return fail(h, "cddpm_op_conv: unsupported shape (ksize %d, C0 %d, C1 %d, Cout %d)", ksize, C0, C1, Cout);
     if (upsample && (H % 2 || W % 2)) return fail(h, "upsample needs even H, W");
+    const bool folded = (upsample == 2);      // upsample: 1 = gather form, 2 = folded 2x2-tap form (what the UNet uses)
+    if (folded && (ksize != 3 || C1 != 0)) return fail(h, "folded upsample needs a 3x3 kernel and a single source");
     hipStream_t s = (hipStream_t)stream;
     HIPCHECK(h, hipSetDevice(h->device));
-    std::vector<float> pk(packed_conv_floats(Cout, Cin, taps));
-    pack_conv_weights(w_host, Cout, Cin, taps, pk.data());
+    std::vector<float> pk(folded ? (size_t)16 * Cout * Cin : packed_conv_floats(Cout, Cin, taps));
+    if (folded) pack_conv_weights_up2(w_host, Cout, Cin, pk.data());
+    else pack_conv_weights(w_host, Cout, Cin, taps, pk.data());
     float *dw = nullptr, *db = nullptr;
     HIPCHECK(h, hipMalloc((void**)&dw, pk.size() * sizeof(float)));
     HIPCHECK(h, hipMalloc((void**)&db, (size_t)Cout * sizeof(float)));
@@ -979,9 +994,9 @@ int cddpm_op_conv(cddpm_handle h, const float* src0, int C0, const float* src1, 
     ConvArgs a;
     zero_conv_args(a);
     a.src0 = src0; a.C0 = C0; a.src1 = src1; a.C1 = C1;
-    a.srcH = upsample ? H / 2 : H; a.srcW = upsample ? W / 2 : W; a.upsample = upsample;
+    a.srcH = upsample ? H / 2 : H; a.srcW = upsample ? W / 2 : W; a.upsample = folded ? 0 : upsample;
     a.coef = coef_dev; a.silu = silu; a.wpk = dw; a.bias = db; a.res = res_dev; a.res_up = res_upsample;
-    a.out = out_dev; a.B = B; a.H = H; a.W = W; a.Cout = Cout; a.taps = taps;
+    a.out = out_dev; a.B = B; a.H = H; a.W = W; a.Cout = Cout; a.taps = folded ? 4 : taps;
     launch_conv(a, s);
     HIPCHECK(h, hipGetLastError());
     HIPCHECK(h, hipStreamSynchronize(s));

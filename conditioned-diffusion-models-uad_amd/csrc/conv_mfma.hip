@@ -20,6 +20,7 @@
 // inside a 8-channel group is therefore {c, c+4} pairs -- identical for A and B, so the sum is unchanged.
 #include "kernels.h"
 #include <cstdlib>
+#include <vector>
 
 namespace cddpm {
 
@@ -55,10 +56,15 @@ template <int TAPS, int NWV>
 __global__ __launch_bounds__(64 * NWV, NWV / 2) void conv_mfma_kernel(const ConvArgs a) {
     constexpr int THREADS = 64 * NWV;
     constexpr int NT = 8 / NWV;                 // 32-cout MFMA tiles per wave: 2 | 1
+    // TAPS == 4 is the folded form of "nearest x2 upsample -> 3x3 conv": an output pixel (2y+a, 2x+b) sees only
+    // 2 x 2 distinct source pixels, so each of the four parity classes (a, b) is a 2x2-tap convolution of the
+    // LOW-resolution input with pre-summed weights (pack_conv_weights_up2): 4/9 of the multiplies, same result up to
+    // the rounding of the weight sums. Tiles then walk the low-resolution grid of one class.
+    constexpr bool UP2 = (TAPS == 4);
     constexpr int PAD = (TAPS == 9) ? 1 : 0;
-    constexpr int PW = 32 + 2 * PAD;            // patch width  (pixels)
-    constexpr int PH = 4 + 2 * PAD;             // patch height (pixels)
-    constexpr int NPIX = PW * PH;               // 204 | 128
+    constexpr int PW = UP2 ? 33 : 32 + 2 * PAD;     // patch width  (pixels)
+    constexpr int PH = UP2 ? 5 : 4 + 2 * PAD;       // patch height (pixels)
+    constexpr int NPIX = PW * PH;                   // 204 | 128 | 165
     constexpr int NK = (NPIX * 8 + THREADS - 1) / THREADS;  // v4f patch entries per thread: 7 | 4 (4 waves), 4 | 2 (8 waves)
     constexpr int WK = 1024 / THREADS;          // v4f of a weight slab per thread: 4 | 2
 
@@ -80,15 +86,20 @@ __global__ __launch_bounds__(64 * NWV, NWV / 2) void conv_mfma_kernel(const Conv
     const int wn = wave >> 1;   // cout block of 32 * NT within the 128
 
     const int ncb = a.Cout >> 7;
-    const int tilesX = (a.W + 31) >> 5;
-    const int tilesY = (a.H + 3) >> 2;
+    // tile grid: the output image, or (UP2) the low-resolution grid of one parity class
+    const int gridH = UP2 ? (a.H >> 1) : a.H, gridW = UP2 ? (a.W >> 1) : a.W;
+    const int tilesX = (gridW + 31) >> 5;
+    const int tilesY = (gridH + 3) >> 2;
     int bid = blockIdx.x;
     const int cb = bid % ncb;
     bid /= ncb;
     const int tx = bid % tilesX;
     bid /= tilesX;
     const int ty = bid % tilesY;
-    const int b = bid / tilesY;
+    bid /= tilesY;
+    const int cls = UP2 ? (bid & 3) : 0;        // parity class: a = cls >> 1 (row), bb = cls & 1 (column)
+    const int b = UP2 ? (bid >> 2) : bid;
+    const int pa = cls >> 1, pb = cls & 1;
     const int y0 = ty * 4, x0 = tx * 32;
 
     const int Cin = a.C0 + a.C1;
@@ -105,14 +116,15 @@ __global__ __launch_bounds__(64 * NWV, NWV / 2) void conv_mfma_kernel(const Conv
     for (int k = 0; k < NK; ++k) {
         const int q = (tid >> 3) + (THREADS / 8) * k;
         const int pr = q / PW, pc = q - pr * PW;
-        const int y = y0 + pr - PAD, x = x0 + pc - PAD;
-        const bool valid = (q < NPIX) && (y >= 0) && (y < a.H) && (x >= 0) && (x < a.W);
-        const int sy = a.upsample ? (y >> 1) : y, sx = a.upsample ? (x >> 1) : x;
+        // UP2: the patch covers low-res rows y0 + a - 1 .. y0 + a + 3 and columns x0 + b - 1 .. x0 + b + 31
+        const int y = UP2 ? (y0 + pr + pa - 1) : (y0 + pr - PAD), x = UP2 ? (x0 + pc + pb - 1) : (x0 + pc - PAD);
+        const bool valid = (q < NPIX) && (y >= 0) && (y < gridH) && (x >= 0) && (x < gridW);
+        const int sy = (!UP2 && a.upsample) ? (y >> 1) : y, sx = (!UP2 && a.upsample) ? (x >> 1) : x;
         psrc[k] = valid ? ((b * a.srcH + sy) * a.srcW + sx) : -1;
         if (valid && (pr >= PAD) && (pr < PH - PAD) && (pc >= PAD) && (pc < PW - PAD)) centre |= 1u << k;
     }
 
-    const v4f* wmain = reinterpret_cast<const v4f*>(a.wpk) + (size_t)cb * nch_main * TAPS * 1024;
+    const v4f* wmain = reinterpret_cast<const v4f*>(a.wpk) + (size_t)(cls * ncb + cb) * nch_main * TAPS * 1024;
     const v4f* wskip = reinterpret_cast<const v4f*>(a.skip_wpk) + (size_t)cb * nch_skip * 1024;
 
     v4f wreg[WK];
@@ -194,8 +206,8 @@ __global__ __launch_bounds__(64 * NWV, NWV / 2) void conv_mfma_kernel(const Conv
     }
 
     auto compute = [&](int tap, int buf) {
-        const int ky = (TAPS == 9) ? (tap / 3) : 0;
-        const int kx = (TAPS == 9) ? (tap - 3 * ky) : 0;
+        const int ky = (TAPS == 9) ? (tap / 3) : (UP2 ? (tap >> 1) : 0);
+        const int kx = (TAPS == 9) ? (tap - 3 * ky) : (UP2 ? (tap & 1) : 0);
         int aoff[2], asw[2];
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
@@ -304,8 +316,9 @@ __global__ __launch_bounds__(64 * NWV, NWV / 2) void conv_mfma_kernel(const Conv
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int p = 8 * (4 * hb + i) + prow;                // 0..63: tile pixel (row p>>5, column p&31)
-                    const int y = y0 + 2 * wm + (p >> 5), x = x0 + (p & 31);
-                    ok[i] = (y < a.H) && (x < a.W);
+                    const int gy = y0 + 2 * wm + (p >> 5), gx = x0 + (p & 31);      // tile-grid coordinates
+                    ok[i] = (gy < gridH) && (gx < gridW);
+                    const int y = UP2 ? (2 * gy + pa) : gy, x = UP2 ? (2 * gx + pb) : gx;   // output pixel
                     oidx[i] = ((size_t)(b * a.H + y) * a.W + x) * a.Cout + co;
                     rsd[i] = v4f{0.f, 0.f, 0.f, 0.f};
                     if (a.res && ok[i]) {
@@ -335,8 +348,8 @@ __global__ __launch_bounds__(64 * NWV, NWV / 2) void conv_mfma_kernel(const Conv
                     ssq.z += __shfl_xor(ssq.z, m, 64); ssq.w += __shfl_xor(ssq.w, m, 64);
                 }
                 if (prow == 0) {
-                    const int nrec = 2 * tilesX * tilesY;
-                    const int rec = 2 * (ty * tilesX + tx) + wm;
+                    const int nrec = (UP2 ? 8 : 2) * tilesX * tilesY;
+                    const int rec = 2 * ((cls * tilesY + ty) * tilesX + tx) + wm;
                     float* o = a.stats + (((size_t)b * nrec + rec) * a.Cout + co) * 2;
                     *reinterpret_cast<v4f*>(o) = v4f{ssum.x, ssq.x, ssum.y, ssq.y};
                     *reinterpret_cast<v4f*>(o + 4) = v4f{ssum.z, ssq.z, ssum.w, ssq.w};
@@ -359,25 +372,31 @@ __global__ __launch_bounds__(64 * NWV, NWV / 2) void conv_mfma_kernel(const Conv
 
 void launch_conv(const ConvArgs& a, hipStream_t stream) {
     static const bool use_ws = [] { const char* e = getenv("CDDPM_CONV_WS"); return e && e[0] == '1'; }();
-    if (use_ws) { launch_conv_ws(a, stream); return; }
+    if (use_ws && a.taps != 4) { launch_conv_ws(a, stream); return; }
     // 4 waves (64 x 64 per wave, 2 waves per SIMD) is the default; CDDPM_CONV_WAVES=8 selects the 8-wave split
     // (64 x 32 per wave, 4 waves per SIMD), which measures the same throughput (tools/conv_ab.py, profiles/)
     static const int nwv = [] { const char* e = getenv("CDDPM_CONV_WAVES"); return (e && e[0] == '8') ? 8 : 4; }();
-    const int tilesX = (a.W + 31) / 32, tilesY = (a.H + 3) / 4;
-    const unsigned grid = (unsigned)(a.B * tilesX * tilesY * (a.Cout / 128));
-    // patch + 2 weight slabs; the epilogue reuses the space as NWV private 8-KB transpose regions
+    const bool up2 = (a.taps == 4);
+    const int gh = up2 ? a.H / 2 : a.H, gw = up2 ? a.W / 2 : a.W;
+    const int tilesX = (gw + 31) / 32, tilesY = (gh + 3) / 4;
+    const unsigned grid = (unsigned)(a.B * (up2 ? 4 : 1) * tilesX * tilesY * (a.Cout / 128));
+    // patch + 2 weight slabs + coefficient cache; the epilogue reuses the space as NWV private 8-KB transpose regions
     const size_t coef_lds = a.coef ? (size_t)3 * (a.C0 + a.C1) * sizeof(float) : 0;
     const size_t need9 = (size_t)(6 * 34 * 8 + 2048) * 16 + coef_lds, need1 = (size_t)(4 * 32 * 8 + 2048) * 16 + coef_lds;
-    if (nwv == 8) {
+    const size_t need4 = (size_t)(5 * 33 * 8 + 2048) * 16 + coef_lds;
+    static bool attr = false;
+    if (!attr) {   // > 64 KB of dynamic LDS needs the opt-in; 80 KB still leaves two workgroups per CU
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_mfma_kernel<9, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_mfma_kernel<1, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_mfma_kernel<9, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_mfma_kernel<1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_mfma_kernel<4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        attr = true;
+    }
+    if (up2) {
+        hipLaunchKernelGGL((conv_mfma_kernel<4, 4>), dim3(grid), dim3(256), need4, stream, a);
+    } else if (nwv == 8) {
         const size_t tr = 8 * 2048 * sizeof(float);
-        static bool attr = false;
-        if (!attr) {   // > 64 KB of dynamic LDS needs the opt-in; 80 KB still leaves two workgroups per CU
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_mfma_kernel<9, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_mfma_kernel<1, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_mfma_kernel<9, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_mfma_kernel<1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-            attr = true;
-        }
         if (a.taps == 9) hipLaunchKernelGGL((conv_mfma_kernel<9, 8>), dim3(grid), dim3(512), need9 > tr ? need9 : tr, stream, a);
         else hipLaunchKernelGGL((conv_mfma_kernel<1, 8>), dim3(grid), dim3(512), need1 > tr ? need1 : tr, stream, a);
     } else {
@@ -404,6 +423,28 @@ void pack_conv_weights(const float* w, int Cout, int Cin, int taps, float* dst) 
                         }
                     }
             }
+}
+
+// Folded weights of "nearest x2 upsample -> 3x3 conv": class (a, b), tap (ty, tx) of the 2x2 low-resolution stencil
+// collects the original taps that land on the same source pixel:
+//   rows  a = 0: ty 0 <- ky {0},    ty 1 <- ky {1, 2};   a = 1: ty 0 <- ky {0, 1}, ty 1 <- ky {2}   (columns alike)
+// dst: [4 classes][Cout/128][Cin/32][4 taps][image], each class packed like pack_conv_weights with taps = 4.
+void pack_conv_weights_up2(const float* w /*[Cout][Cin][3][3]*/, int Cout, int Cin, float* dst) {
+    std::vector<float> wf((size_t)Cout * Cin * 4);
+    for (int cls = 0; cls < 4; ++cls) {
+        const int pa = cls >> 1, pb = cls & 1;
+        for (size_t oc = 0; oc < (size_t)Cout * Cin; ++oc)
+            for (int ty = 0; ty < 2; ++ty)
+                for (int tx = 0; tx < 2; ++tx) {
+                    const int ky0 = pa == 0 ? (ty == 0 ? 0 : 1) : (ty == 0 ? 0 : 2), ky1 = pa == 0 ? (ty == 0 ? 0 : 2) : (ty == 0 ? 1 : 2);
+                    const int kx0 = pb == 0 ? (tx == 0 ? 0 : 1) : (tx == 0 ? 0 : 2), kx1 = pb == 0 ? (tx == 0 ? 0 : 2) : (tx == 0 ? 1 : 2);
+                    double acc = 0.0;    // summed in double, rounded once
+                    for (int ky = ky0; ky <= ky1; ++ky)
+                        for (int kx = kx0; kx <= kx1; ++kx) acc += (double)w[oc * 9 + ky * 3 + kx];
+                    wf[oc * 4 + ty * 2 + tx] = (float)acc;
+                }
+        pack_conv_weights(wf.data(), Cout, Cin, 4, dst + (size_t)cls * Cout * Cin * 4);
+    }
 }
 
 }  // namespace cddpm

@@ -24,7 +24,8 @@ struct ConvArgs {
     int res_up;          // 1: residual lives at half resolution, read at (y>>1, x>>1)
     float* out;          // NHWC [B, H, W, Cout]
     int B, H, W, Cout;   // Cout multiple of 128
-    int taps;            // 9 (3x3, zero pad 1) or 1
+    int taps;            // 9 (3x3, zero pad 1), 1, or 4 = folded 'nearest x2 upsample -> 3x3' (src at half resolution,
+                         // weights from pack_conv_weights_up2, upsample flag unused)
     // second K segment (optional): an un-normalised 1x1 convolution accumulated into the same tile,
     // used for ResBlock skip_connection convs: out += conv1x1(skip0|skip1) (bias folded by the caller)
     const float* skip0; const float* skip1; int S0, S1;   // NHWC at the OUTPUT resolution
@@ -35,6 +36,7 @@ struct ConvArgs {
     float* stats;
 };
 inline int conv_stat_records(int H, int W) { return 2 * ((W + 31) / 32) * ((H + 3) / 4); }
+inline int conv_stat_records_up2(int H, int W) { return 8 * ((W / 2 + 31) / 32) * ((H / 2 + 3) / 4); }
 void launch_conv(const ConvArgs& a, hipStream_t stream);
 // wave-specialised persistent variant (conv_ws.hip); launch_conv forwards to it when CDDPM_CONV_WS=1 is set
 void launch_conv_ws(const ConvArgs& a, hipStream_t stream);
@@ -43,6 +45,8 @@ void launch_conv_ws(const ConvArgs& a, hipStream_t stream);
 // layout: [Cout/128][Cin/32][taps][128 rows x 8 slots of float4], slot s of row j stored at s ^ ((j>>1)&7)
 size_t packed_conv_floats(int Cout, int Cin, int taps);
 void pack_conv_weights(const float* w /*[Cout][Cin][k][k]*/, int Cout, int Cin, int taps, float* dst);
+// folded weights of nearest-x2-upsample + 3x3: 4 parity classes x 4 taps, 16/9 of the original size
+void pack_conv_weights_up2(const float* w /*[Cout][Cin][3][3]*/, int Cout, int Cin, float* dst);
 
 // ------------------------------------------------------------------------------------------------
 // GroupNorm(32) statistics and per-(sample, channel) coefficients (norm_kernels.hip)

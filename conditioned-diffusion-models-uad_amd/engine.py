@@ -268,7 +268,7 @@ class CddpmEngine:
     def op_conv(self, src0, src1, coef, silu, upsample, weight, bias, res, res_upsample, ksize):
         """fused conv on NHWC device tensors (see cddpm_op_conv); weight [Cout,Cin,k,k] host/any tensor."""
         B, h, w, C0 = src0.shape
-        H, W = (2 * h, 2 * w) if upsample else (h, w)
+        H, W = (2 * h, 2 * w) if upsample else (h, w)     # upsample: 0 none, 1 gather form, 2 folded form
         C1 = src1.shape[-1] if src1 is not None else 0
         wt = np.ascontiguousarray(weight.detach().cpu().numpy(), dtype=np.float32)
         bs = np.ascontiguousarray(bias.detach().cpu().numpy(), dtype=np.float32)

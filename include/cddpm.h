@@ -150,7 +150,8 @@ int cddpm_block_shape(cddpm_handle h, int block, int H, int W, int* C, int* h_ou
 
 /* standalone fused convolution on NHWC tensors (the kernel behind every ResBlock conv), for kernel tests:
  * out[B,H,W,Cout] = conv_k(act(cat[src0,src1])) + bias (+ res), k in {1,3}, zero padding k/2, optional
- * nearest x2 upsampling of the sources (srcs are then [B,H/2,W/2,*]) and of the residual.
+ * nearest x2 upsampling of the sources (srcs are then [B,H/2,W/2,*]; upsample = 1: gather form, 2: the folded form the
+ * UNet uses -- four 2x2-tap convolutions of the low-resolution input with pre-summed weights) and of the residual.
  * act(v) = silu?( (v - mean[b,c]) * a[b,c] + d[b,c] ) when coef_dev != NULL (coef_dev = [3][B][Cin]: mean, a, d).
  * w_host is PyTorch layout [Cout,Cin,k,k]. */
 int cddpm_op_conv(cddpm_handle h, const float* src0_dev, int C0, const float* src1_dev, int C1,

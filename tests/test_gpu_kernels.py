@@ -81,6 +81,8 @@ CONV_CASES = [
     ("3x3_act_res", 128, 0, 128, 3, 12, 20, True, True, False, "same"),
     ("3x3_concat", 256, 128, 256, 3, 8, 40, True, True, False, "none"),
     ("3x3_up", 256, 0, 256, 3, 16, 24, True, True, True, "up"),
+    ("3x3_up_folded", 256, 0, 256, 3, 16, 24, True, True, 2, "up"),
+    ("3x3_up_folded_wide", 128, 0, 128, 3, 24, 80, True, True, 2, "none"),
     ("1x1_qkv", 256, 0, 768, 1, 8, 8, True, False, False, "none"),
     ("1x1_proj_res", 256, 0, 256, 1, 12, 36, False, False, False, "same"),
     ("3x3_wide", 128, 0, 256, 3, 4, 96, False, False, False, "none"),
@@ -114,7 +116,7 @@ def test_conv(eng, case):
     elif resmode == "up":
         res = torch.randn(B, Cout, H // 2, W // 2)
         ref = ref + F.interpolate(res, scale_factor=2, mode="nearest")
-    got = eng.op_conv(nhwc(x[:, :C0]), nhwc(x[:, C0:]) if C1 else None, coef.cuda() if use_coef else None, silu, up,
+    got = eng.op_conv(nhwc(x[:, :C0]), nhwc(x[:, C0:]) if C1 else None, coef.cuda() if use_coef else None, silu, int(up),
                       wt, bias, nhwc(res) if res is not None else None, resmode == "up", k)
     close(nchw(got), ref)
 
