@@ -67,7 +67,8 @@ LOOPS = [("loop_B2_32x32_T1000_start8", 1000, 8, 2, 32, 32, 0),
          ("loop_B2_32x32_T50_start0", 50, 0, 2, 32, 32, 0),
          ("loop_B3_32x48_T1000_start5_slice7", 1000, 5, 3, 32, 48, 7),
          ("loop_cfg1_B4_128x128_T50_start0", 50, 0, 4, 128, 128, 0),
-         ("loop_B1_128x128_T1000_start50", 1000, 50, 1, 128, 128, 0)]
+         ("loop_B1_128x128_T1000_start50", 1000, 50, 1, 128, 128, 0),
+         ("loop_B2_32x32_T1000_start0", 1000, 0, 2, 32, 32, 0)]       # the FULL T = 1000 chain from pure noise
 
 
 @pytest.mark.parametrize("name,T,start_t,B,H,W,slice0", LOOPS, ids=[l[0] for l in LOOPS])
