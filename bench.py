@@ -175,7 +175,7 @@ def main():
                 traffic = json.load(open(tfile)).get("bytes_per_launch")
             except Exception:
                 traffic = None
-        out["roofline"] = {"bound": "mfma", "kernel": "conv_mfma_kernel<9> (fused GN/FiLM/SiLU + 3x3 conv + skip, fp32 MFMA)",
+        out["roofline"] = {"bound": "mfma", "kernel": "conv_mfma_kernel<9,4> and <4,4> (fused GN/FiLM/SiLU + 3x3 conv [+ folded upsample] + skip + GN statistics, fp32 MFMA); FLOPs = executed",
                            "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                            "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
                            "launches": c3["launches"], "avg_launch_ms": c3["ms"] / max(1, c3["launches"]),
