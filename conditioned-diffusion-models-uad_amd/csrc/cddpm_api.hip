@@ -752,7 +752,7 @@ int cddpm_load_weights(cddpm_handle h, const char* const* names, const float* co
             // the upsampled tensor is never built: Upsample(nearest x2) + Conv3x3 (OpenAI_Unet.py:118-128, :289-293) is
             // evaluated as four 2x2-tap convolutions of the low-resolution input (4/9 of the multiplies)
             r.conv1.Cin = r.Cin; r.conv1.Cout = r.Cout; r.conv1.taps = 4;
-            std::vector<float> pk((size_t)16 * r.Cout * r.Cin);
+            std::vector<float> pk(4 * packed_conv_floats(r.Cout, r.Cin, 4));
             pack_conv_weights_up2(hw.get(r.prefix + ".in_layers.2.weight"), r.Cout, r.Cin, pk.data());
             if (upload(h, &r.conv1_up2, pk.data(), pk.size())) return -1;
             if (upload(h, &r.conv1.bias, hw.get(r.prefix + ".in_layers.2.bias"), r.Cout)) return -1;
@@ -983,7 +983,7 @@ int cddpm_op_conv(cddpm_handle h, const float* src0, int C0, const float* src1, 
     if (folded && (ksize != 3 || C1 != 0)) return fail(h, "folded upsample needs a 3x3 kernel and a single source");
     hipStream_t s = (hipStream_t)stream;
     HIPCHECK(h, hipSetDevice(h->device));
-    std::vector<float> pk(folded ? (size_t)16 * Cout * Cin : packed_conv_floats(Cout, Cin, taps));
+    std::vector<float> pk(folded ? 4 * packed_conv_floats(Cout, Cin, 4) : packed_conv_floats(Cout, Cin, taps));
     if (folded) pack_conv_weights_up2(w_host, Cout, Cin, pk.data());
     else pack_conv_weights(w_host, Cout, Cin, taps, pk.data());
     float *dw = nullptr, *db = nullptr;
@@ -1015,7 +1015,7 @@ int cddpm_op_conv_bench(cddpm_handle h, int C0, int C1, int Cout, int ksize, int
     hipStream_t s = nullptr;
     const int sh = upsample ? H / 2 : H, sw = upsample ? W / 2 : W;
     const size_t n0 = (size_t)B * sh * sw * C0, n1 = (size_t)B * sh * sw * C1, nout = (size_t)B * H * W * Cout;
-    const size_t nsk = (size_t)B * H * W * skipC, nw = (size_t)Cout * Cin * taps, nws = (size_t)Cout * skipC;
+    const size_t nsk = (size_t)B * H * W * skipC;
     const size_t nres = res_mode == 2 ? nout / 4 : nout;
     float *x0 = nullptr, *x1 = nullptr, *out = nullptr, *res = nullptr, *sk = nullptr, *w = nullptr, *ws = nullptr, *cf = nullptr, *bs = nullptr;
     unsigned long long* stamps = nullptr;
@@ -1030,7 +1030,18 @@ int cddpm_op_conv_bench(cddpm_handle h, int C0, int C1, int Cout, int ksize, int
     };
     int rc = 0;
     rc |= alloc_fill(&x0, n0, 1, 1.f); rc |= alloc_fill(&x1, n1, 2, 1.f); rc |= alloc_fill(&sk, nsk, 3, 1.f);
-    rc |= alloc_fill(&w, nw, 4, 1.f); rc |= alloc_fill(&ws, nws, 5, 1.f); rc |= alloc_fill(&cf, (size_t)3 * B * Cin, 6, 1.f);
+    // weights: random host values through the packer of the active kernel family (fp32 image or bf16 x 3 image)
+    auto pack_upload = [&](float** p, int cin, int tp, uint64_t seed) -> int {
+        if (!cin) return 0;
+        std::vector<float> hwt((size_t)Cout * cin * tp);
+        uint64_t st = seed;
+        for (float& v : hwt) { st = st * 6364136223846793005ull + 1442695040888963407ull; v = ((int64_t)(st >> 33) - (1ll << 30)) * (0.05f / (1ll << 30)); }
+        std::vector<float> pk(packed_conv_floats(Cout, cin, tp));
+        pack_conv_weights(hwt.data(), Cout, cin, tp, pk.data());
+        if (hipMalloc((void**)p, pk.size() * sizeof(float)) != hipSuccess) return -1;
+        return hipMemcpy(*p, pk.data(), pk.size() * sizeof(float), hipMemcpyHostToDevice) == hipSuccess ? 0 : -1;
+    };
+    rc |= pack_upload(&w, Cin, taps, 4); rc |= pack_upload(&ws, skipC, 1, 5); rc |= alloc_fill(&cf, (size_t)3 * B * Cin, 6, 1.f);
     rc |= alloc_fill(&bs, Cout, 7, 1.f);
     if (res_mode) rc |= alloc_fill(&res, nres, 8, 1.f);
     if (hipMalloc((void**)&out, nout * sizeof(float)) != hipSuccess) rc = -1;

@@ -1,0 +1,437 @@
+// Fused implicit-GEMM convolution for gfx950 (MI355X): fp32 accuracy on the bf16 matrix pipe.
+//
+// Same operator as conv_mfma.hip (see there for what is fused and the reference lines it replaces:
+// src/models/modules/OpenAI_Unet.py:284-338, :386-394, :118-128, :948), same arguments, same results to fp32
+// rounding. What changes is how a product of two fp32 numbers reaches the accumulator:
+//
+//   every fp32 operand is split EXACTLY into three bf16 terms, x = hi + mid + lo (round-to-nearest at each step:
+//   hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid); 3 x 8 significant bits cover fp32's 24), and
+//   a * b = hi*hi + hi*mid + mid*hi + mid*mid + hi*lo + lo*hi   (+ terms below 2^-24 |a b|, dropped).
+//   Each bf16 x bf16 product is exact in fp32 and v_mfma_f32_32x32x16_bf16 accumulates in fp32, so the six MFMAs
+//   carry the same information as one fp32 FMA chain -- measured against fp64 the result is slightly BETTER than
+//   the fp32 MFMA (v_mfma_f32_32x32x2_f32) path: rms error 2.9e-7 vs 3.2e-7 of rms(C) at K = 4608, both folded per
+//   32-channel chunk; tools/ubench/bf16_split_accuracy.hip. The bf16 pipe runs 16x the fp32 pipe's rate
+//   (2.5 PFLOP/s vs 157 TFLOP/s dense), so six bf16 MFMAs cost 6/16 of the fp32 MFMAs they replace.
+//
+// GEMM view:  D[pixel][cout] = sum_{tap, ci} act(X)[pixel + tap][ci] * Wt[tap][ci][cout]
+//   M = 256 pixels (8 image rows x 32 columns), N = 128 output channels, K step = 32 input channels x 1 tap
+//   = 2 MFMA k-steps of 16. 8 waves (2 per SIMD), each owns 64 pixels x 64 couts = 2 x 2 MFMA tiles.
+// LDS (one workgroup per CU, <= 124 KB):
+//   act patch   : (8+2) x (32+2) pixels, per pixel 3 splits x 32 channels bf16 = 12 slots of 16 B;
+//                 slot (split s, u = channel / 8) stored at 4 s + (u ^ ((pixel >> 2) & 3))
+//   weight slab : 2 buffers x [128 cout][12 slots], same addressing; the packed global image (host-split weights,
+//                 pack_conv_weights_x6) IS the LDS image, so staging is a linear 16-B copy
+//   With a 12-slot pixel stride, 16 consecutive pixels x one slot cover all 16 four-bank groups: ds_read_b128 of a
+//   fragment is bank-conflict free.
+// A lane's 16-B fragment = 8 consecutive channels = its K elements of one k-step (lane>>5 selects the half).
+#include "kernels.h"
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+namespace cddpm {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float silu_x6(float v) {
+    // identical evaluation to conv_mfma.hip::silu_f (split-product exp2, ~1.5 ulp)
+    const float t = fminf(-v * 1.44269502162933349609375f, 126.0f);
+    float tl = __builtin_fmaf(-v, 1.44269502162933349609375f, -t);
+    tl = __builtin_fmaf(-v, 1.925963033500011e-08f, tl);
+    tl = (t < 126.0f) ? tl : 0.0f;
+    float e = __builtin_amdgcn_exp2f(t);
+    e = __builtin_fmaf(e, tl * 0.693147180559945f, e);
+    return v * __builtin_amdgcn_rcpf(1.0f + e);
+}
+
+// exact three-way split of four fp32 values into bf16 quads (8 B each)
+__device__ __forceinline__ void split3x4(const v4f v, bf16x4& h, bf16x4& m, bf16x4& l) {
+    h = __builtin_convertvector(v, bf16x4);
+    const v4f r1 = v - __builtin_convertvector(h, v4f);
+    m = __builtin_convertvector(r1, bf16x4);
+    const v4f r2 = r1 - __builtin_convertvector(m, v4f);
+    l = __builtin_convertvector(r2, bf16x4);
+}
+
+template <int TAPS, int ROWS>
+__global__ __launch_bounds__(64 * ROWS) void conv_x6_kernel(const ConvArgs a) {
+    constexpr int THREADS = 64 * ROWS;
+    // TAPS == 4: folded "nearest x2 upsample -> 3x3 conv", one parity class of the output per tile (see conv_mfma.hip)
+    constexpr bool UP2 = (TAPS == 4);
+    constexpr int PAD = (TAPS == 9) ? 1 : 0;
+    constexpr int PW = UP2 ? 33 : 32 + 2 * PAD;         // patch width  (pixels)
+    constexpr int PH = UP2 ? ROWS + 1 : ROWS + 2 * PAD; // patch height (pixels)
+    constexpr int NPIX = PW * PH;                       // 340 | 256 | 297 at ROWS = 8
+    constexpr int NK = (NPIX * 8 + THREADS - 1) / THREADS;   // 16-B (4-channel) patch entries per thread: 6 | 4 | 5
+    constexpr int WSLOTS = 128 * 12;                    // 16-B slots of a weight slab
+    constexpr int WK = WSLOTS / THREADS;                // per thread: 3
+    static_assert(WSLOTS % THREADS == 0, "weight slab must divide evenly");
+
+    extern __shared__ v4f lds[];
+    v4f* ldsA = lds;                    // NPIX * 12 slots
+    v4f* ldsW = lds + NPIX * 12;        // 2 * WSLOTS
+    v4f* ldsC = ldsW + 2 * WSLOTS;      // GroupNorm/FiLM coefficients of this sample (3 x Cin floats)
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int li = lane & 31;
+    const int lh = lane >> 5;
+    const int wm = wave % (ROWS / 2);   // pixel rows {2 wm, 2 wm + 1} of the tile
+    const int wn = wave / (ROWS / 2);   // cout half
+
+    const int ncb = a.Cout >> 7;
+    const int gridH = UP2 ? (a.H >> 1) : a.H, gridW = UP2 ? (a.W >> 1) : a.W;
+    const int tilesX = (gridW + 31) >> 5;
+    const int tilesY = (gridH + ROWS - 1) / ROWS;
+    int bid = blockIdx.x;
+    const int cb = bid % ncb;
+    bid /= ncb;
+    const int tx = bid % tilesX;
+    bid /= tilesX;
+    const int ty = bid % tilesY;
+    bid /= tilesY;
+    const int cls = UP2 ? (bid & 3) : 0;
+    const int b = UP2 ? (bid >> 2) : bid;
+    const int pa = cls >> 1, pb = cls & 1;
+    const int y0 = ty * ROWS, x0 = tx * 32;
+
+    const int Cin = a.C0 + a.C1;
+    const int nch_main = Cin >> 5;
+    const int nch_skip = (a.S0 + a.S1) >> 5;
+    const int nch = nch_main + nch_skip;
+
+    // ---- per-thread patch entries: channel quad c4 is fixed per thread, pixel q = (tid>>3) + (THREADS/8) k
+    const int c4 = tid & 7;
+    int psrc[NK];
+    unsigned centre = 0;
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+        const int q = (tid >> 3) + (THREADS / 8) * k;
+        const int pr = q / PW, pc = q - pr * PW;
+        const int y = UP2 ? (y0 + pr + pa - 1) : (y0 + pr - PAD), x = UP2 ? (x0 + pc + pb - 1) : (x0 + pc - PAD);
+        const bool valid = (q < NPIX) && (y >= 0) && (y < gridH) && (x >= 0) && (x < gridW);
+        const int sy = (!UP2 && a.upsample) ? (y >> 1) : y, sx = (!UP2 && a.upsample) ? (x >> 1) : x;
+        psrc[k] = valid ? ((b * a.srcH + sy) * a.srcW + sx) : -1;
+        if (valid && (pr >= PAD) && (pr < PH - PAD) && (pc >= PAD) && (pc < PW - PAD)) centre |= 1u << k;
+    }
+
+    const v4f* wmain = reinterpret_cast<const v4f*>(a.wpk) + (size_t)(cls * ncb + cb) * nch_main * TAPS * WSLOTS;
+    const v4f* wskip = reinterpret_cast<const v4f*>(a.skip_wpk) + (size_t)cb * nch_skip * WSLOTS;
+
+    v4f wreg[WK];
+    v4f areg[NK];
+    const bool have_coef = (a.coef != nullptr);
+
+    auto wslab = [&](int chunk, int tap) -> const v4f* {
+        if (chunk >= nch) { chunk = 0; tap = 0; }      // past the end: wrap, so the prefetch stays unconditional
+        return (chunk < nch_main) ? (wmain + ((size_t)chunk * TAPS + tap) * WSLOTS)
+                                  : (wskip + (size_t)(chunk - nch_main) * WSLOTS);
+    };
+    auto load_act = [&](int chunk) {
+        const float* base;
+        int Cs, c0;
+        const bool main_seg = chunk < nch_main;
+        if (main_seg) {
+            const int ch = chunk << 5;
+            if (ch < a.C0) { base = a.src0; Cs = a.C0; c0 = ch; }
+            else           { base = a.src1; Cs = a.C1; c0 = ch - a.C0; }
+        } else {
+            const int ch = (chunk - nch_main) << 5;
+            if (ch < a.S0) { base = a.skip0; Cs = a.S0; c0 = ch; }
+            else           { base = a.skip1; Cs = a.S1; c0 = ch - a.S0; }
+        }
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+            const int p = (main_seg || ((centre >> k) & 1u)) ? psrc[k] : -1;
+            v4f v = v4f{0.f, 0.f, 0.f, 0.f};
+            if (p >= 0) v = *reinterpret_cast<const v4f*>(base + (size_t)p * Cs + c0 + 4 * c4);
+            areg[k] = v;
+        }
+    };
+    auto store_act = [&](int chunk) {
+        const bool main_seg = chunk < nch_main;
+        const bool do_silu = main_seg && a.silu;
+        v4f cm = v4f{0.f, 0.f, 0.f, 0.f}, ca = v4f{1.f, 1.f, 1.f, 1.f}, cd = cm;
+        const bool aff = main_seg && have_coef;
+        if (aff) {
+            const int ci = (chunk << 3) + c4;
+            cm = ldsC[ci];
+            ca = ldsC[(Cin >> 2) + ci];
+            cd = ldsC[2 * (Cin >> 2) + ci];
+        }
+        v2f* dst = reinterpret_cast<v2f*>(ldsA);       // 8-B units
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+            v4f v = areg[k];
+            const int p = (main_seg || ((centre >> k) & 1u)) ? psrc[k] : -1;
+            if (p >= 0) {   // zero padding stays exactly zero: the conv pads AFTER the activation
+                if (aff) v = (v - cm) * ca + cd;
+                if (do_silu) { v.x = silu_x6(v.x); v.y = silu_x6(v.y); v.z = silu_x6(v.z); v.w = silu_x6(v.w); }
+            }
+            const int q = (tid >> 3) + (THREADS / 8) * k;
+            if (q < NPIX) {
+                bf16x4 h, m, l;
+                split3x4(v, h, m, l);
+                // 4 channels = half a slot: slot u = c4 >> 1 of each split, half c4 & 1
+                const int o = (q * 12 + ((c4 >> 1) ^ ((q >> 2) & 3))) * 2 + (c4 & 1);
+                dst[o] = __builtin_bit_cast(v2f, h);
+                dst[o + 8] = __builtin_bit_cast(v2f, m);
+                dst[o + 16] = __builtin_bit_cast(v2f, l);
+            }
+        }
+    };
+
+    // Two-level accumulation as in conv_mfma.hip: `acc` collects one 32-channel chunk, `tot` sums the chunks.
+    f32x16 acc[2][2], tot[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; tot[i][j][r] = 0.f; }
+
+    // B operand (weights) LDS offsets: row j = cout within the 128 block
+    int boff[2], bsw[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int j = 64 * wn + 32 * nt + li;
+        boff[nt] = j * 12;
+        bsw[nt] = (j >> 2) & 3;
+    }
+
+#define X6_MFMA4(A, B)                                                                                     \
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0], B[0], acc[0][0], 0, 0, 0);                   \
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0], B[1], acc[0][1], 0, 0, 0);                   \
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[1], B[0], acc[1][0], 0, 0, 0);                   \
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[1], B[1], acc[1][1], 0, 0, 0);
+
+    auto compute = [&](int tap, int buf) {
+        const int ky = (TAPS == 9) ? (tap / 3) : (UP2 ? (tap >> 1) : 0);
+        const int kx = (TAPS == 9) ? (tap - 3 * ky) : (UP2 ? (tap & 1) : 0);
+        int aoff[2], asw[2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const int q = (2 * wm + mt + ky) * PW + li + kx;
+            aoff[mt] = q * 12;
+            asw[mt] = (q >> 2) & 3;
+        }
+        const v4f* wb = ldsW + buf * WSLOTS;
+        auto A = [&](int mt, int s, int u) -> bf16x8 { return __builtin_bit_cast(bf16x8, ldsA[aoff[mt] + 4 * s + (u ^ asw[mt])]); };
+        auto Bf = [&](int nt, int s, int u) -> bf16x8 { return __builtin_bit_cast(bf16x8, wb[boff[nt] + 4 * s + (u ^ bsw[nt])]); };
+#pragma unroll
+        for (int jk = 0; jk < 2; ++jk) {
+            const int u = 2 * jk + lh;
+            bf16x8 ah[2], am[2], al[2], bh[2], bm[2], bl[2];
+            ah[0] = A(0, 0, u); ah[1] = A(1, 0, u);
+            bh[0] = Bf(0, 0, u); bh[1] = Bf(1, 0, u);
+            bm[0] = Bf(0, 1, u); bm[1] = Bf(1, 1, u);
+            am[0] = A(0, 1, u); am[1] = A(1, 1, u);
+            bl[0] = Bf(0, 2, u); bl[1] = Bf(1, 2, u);
+            al[0] = A(0, 2, u); al[1] = A(1, 2, u);
+            // smallest terms first
+#ifdef CDDPM_X9      // diagnostic build: all nine partial products (the three dropped ones are below 2^-24 |a b|)
+            X6_MFMA4(al, bl)
+            X6_MFMA4(am, bl)
+            X6_MFMA4(al, bm)
+#endif
+            X6_MFMA4(al, bh)
+            X6_MFMA4(ah, bl)
+            X6_MFMA4(am, bm)
+            X6_MFMA4(am, bh)
+            X6_MFMA4(ah, bm)
+            X6_MFMA4(ah, bh)
+        }
+    };
+
+    // ---- main loop: weights double-buffered in LDS and prefetched through registers one stage ahead;
+    //      the next chunk's patch is fetched into registers behind the last tap's MFMAs.
+    {
+        const v4f* p0 = wslab(0, 0);
+#pragma unroll
+        for (int i = 0; i < WK; ++i) wreg[i] = p0[tid + THREADS * i];
+    }
+    load_act(0);
+    if (have_coef) {
+        const int nq = Cin >> 2;
+        const size_t plane = (size_t)a.B * Cin;
+        for (int i = tid; i < 3 * nq; i += THREADS) {
+            const int pl = i / nq, cq = i - pl * nq;
+            ldsC[i] = *reinterpret_cast<const v4f*>(a.coef + pl * plane + (size_t)b * Cin + 4 * cq);
+        }
+    }
+    int buf = 0;
+    for (int chunk = 0; chunk < nch; ++chunk) {
+        const bool main_seg = chunk < nch_main;
+        const int ntap = main_seg ? TAPS : 1;
+        __syncthreads();   // every wave is done reading the previous patch
+        store_act(chunk);
+        for (int t = 0; t < ntap; ++t) {
+#pragma unroll
+            for (int i = 0; i < WK; ++i) ldsW[buf * WSLOTS + tid + THREADS * i] = wreg[i];
+            const bool last_tap = (t == ntap - 1);
+            const v4f* pn = last_tap ? wslab(chunk + 1, 0) : wslab(chunk, t + 1);
+#pragma unroll
+            for (int i = 0; i < WK; ++i) wreg[i] = pn[tid + THREADS * i];
+            if (last_tap && chunk + 1 < nch) load_act(chunk + 1);
+            __syncthreads();
+            compute(main_seg ? t : (TAPS / 2), buf);   // skip segment: centre tap
+            buf ^= 1;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                tot[i][j] += acc[i][j];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            }
+    }
+#undef X6_MFMA4
+
+    __syncthreads();   // every wave is done with the patch / weight buffers before they become transpose space
+    // ---- epilogue: as conv_mfma.hip -- each wave transposes its 64 x 64 tile through a private 8-KB LDS region so
+    //      that every lane moves 16 B; bias, residual and the GroupNorm statistics of the output are applied here.
+    {
+        float* tr = reinterpret_cast<float*>(lds) + wave * 2048;      // [64 pixels][32 channels]
+        const int cq = lane & 7;
+        const int prow = lane >> 3;
+        const int tilesY4 = (gridH + 3) >> 2;                         // statistics records are per 4-row band (kernels.h)
+        const int ty4 = (y0 >> 2) + (wm >> 1);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int co = cb * 128 + 64 * wn + 32 * nt + 4 * cq;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    tr[(mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * 32 + li] = tot[mt][nt][r];
+            __builtin_amdgcn_wave_barrier();
+            const v4f bias = a.bias ? *reinterpret_cast<const v4f*>(a.bias + co) : v4f{0.f, 0.f, 0.f, 0.f};
+            v4f ssum = v4f{0.f, 0.f, 0.f, 0.f}, ssq = ssum;
+#pragma unroll
+            for (int hb = 0; hb < 2; ++hb) {
+                v4f val[4], rsd[4];
+                size_t oidx[4];
+                bool ok[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int p = 8 * (4 * hb + i) + prow;
+                    const int gy = y0 + 2 * wm + (p >> 5), gx = x0 + (p & 31);
+                    ok[i] = (gy < gridH) && (gx < gridW);
+                    const int y = UP2 ? (2 * gy + pa) : gy, x = UP2 ? (2 * gx + pb) : gx;
+                    oidx[i] = ((size_t)(b * a.H + y) * a.W + x) * a.Cout + co;
+                    rsd[i] = v4f{0.f, 0.f, 0.f, 0.f};
+                    if (a.res && ok[i]) {
+                        const size_t rp = a.res_up ? ((size_t)(b * (a.H >> 1) + (y >> 1)) * (a.W >> 1) + (x >> 1))
+                                                   : ((size_t)(b * a.H + y) * a.W + x);
+                        rsd[i] = *reinterpret_cast<const v4f*>(a.res + rp * a.Cout + co);
+                    }
+                    val[i] = *reinterpret_cast<const v4f*>(tr + p * 32 + 4 * cq);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (ok[i]) {
+                        const v4f o = val[i] + bias + rsd[i];
+                        *reinterpret_cast<v4f*>(a.out + oidx[i]) = o;
+                        ssum += o;
+                        ssq += o * o;
+                    }
+            }
+            if (a.stats) {
+#pragma unroll
+                for (int m = 8; m < 64; m <<= 1) {
+                    ssum.x += __shfl_xor(ssum.x, m, 64); ssum.y += __shfl_xor(ssum.y, m, 64);
+                    ssum.z += __shfl_xor(ssum.z, m, 64); ssum.w += __shfl_xor(ssum.w, m, 64);
+                    ssq.x += __shfl_xor(ssq.x, m, 64); ssq.y += __shfl_xor(ssq.y, m, 64);
+                    ssq.z += __shfl_xor(ssq.z, m, 64); ssq.w += __shfl_xor(ssq.w, m, 64);
+                }
+                if (prow == 0 && ty4 < tilesY4) {
+                    const int nrec = (UP2 ? 8 : 2) * tilesX * tilesY4;
+                    const int rec = 2 * ((cls * tilesY4 + ty4) * tilesX + tx) + (wm & 1);
+                    float* o = a.stats + (((size_t)b * nrec + rec) * a.Cout + co) * 2;
+                    *reinterpret_cast<v4f*>(o) = v4f{ssum.x, ssq.x, ssum.y, ssq.y};
+                    *reinterpret_cast<v4f*>(o + 4) = v4f{ssum.z, ssq.z, ssum.w, ssq.w};
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
+bool conv_x6_enabled() {
+    static const bool on = [] { const char* e = getenv("CDDPM_CONV"); return e && strcmp(e, "x6") == 0; }();
+    return on;
+}
+
+void launch_conv_x6(const ConvArgs& a, hipStream_t stream) {
+    constexpr int ROWS = 8;
+    const bool up2 = (a.taps == 4);
+    const int gh = up2 ? a.H / 2 : a.H, gw = up2 ? a.W / 2 : a.W;
+    const int tilesX = (gw + 31) / 32, tilesY = (gh + ROWS - 1) / ROWS;
+    const unsigned grid = (unsigned)(a.B * (up2 ? 4 : 1) * tilesX * tilesY * (a.Cout / 128));
+    const size_t coef_lds = a.coef ? (size_t)3 * (a.C0 + a.C1) * sizeof(float) : 0;
+    auto need = [&](int npix) {
+        const size_t main = (size_t)(npix * 12 + 2 * 128 * 12) * 16 + coef_lds;
+        const size_t tr = (size_t)ROWS * 2048 * sizeof(float);      // epilogue transpose regions alias the buffers
+        return main > tr ? main : tr;
+    };
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_x6_kernel<9, ROWS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_x6_kernel<1, ROWS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_x6_kernel<4, ROWS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr = true;
+    }
+    if (a.taps == 9) hipLaunchKernelGGL((conv_x6_kernel<9, ROWS>), dim3(grid), dim3(64 * ROWS), need((ROWS + 2) * 34), stream, a);
+    else if (a.taps == 1) hipLaunchKernelGGL((conv_x6_kernel<1, ROWS>), dim3(grid), dim3(64 * ROWS), need(ROWS * 32), stream, a);
+    else hipLaunchKernelGGL((conv_x6_kernel<4, ROWS>), dim3(grid), dim3(64 * ROWS), need((ROWS + 1) * 33), stream, a);
+}
+
+// ---- host side: bf16 round-to-nearest-even and the three-way split
+static inline uint16_t bf16_rne(float x) {
+    uint32_t u;
+    memcpy(&u, &x, 4);
+    if ((u & 0x7f800000u) == 0x7f800000u) return (uint16_t)(u >> 16);     // inf / nan: truncate (weights are finite)
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+static inline float bf16_to_f(uint16_t h) {
+    const uint32_t u = (uint32_t)h << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
+// w: PyTorch [Cout][Cin][k][k] (taps = k*k) -> [Cout/128][Cin/32][taps][128 rows][12 slots][8 bf16]:
+// slot (split s, u = channel/8 within the chunk) of row j stored at 4 s + (u ^ ((j>>2)&3)); 6 bytes per weight.
+void pack_conv_weights_x6(const float* w, int Cout, int Cin, int taps, void* dst_) {
+    uint16_t* dst = static_cast<uint16_t*>(dst_);
+    const int ncb = Cout / 128, nch = Cin / 32;
+    for (int cb = 0; cb < ncb; ++cb)
+        for (int ch = 0; ch < nch; ++ch)
+            for (int t = 0; t < taps; ++t) {
+                uint16_t* img = dst + (((size_t)cb * nch + ch) * taps + t) * (128 * 12 * 8);
+                for (int j = 0; j < 128; ++j)
+                    for (int u = 0; u < 4; ++u)
+                        for (int e = 0; e < 8; ++e) {
+                            const int co = cb * 128 + j, ci = ch * 32 + 8 * u + e;
+                            const float x = w[((size_t)co * Cin + ci) * taps + t];
+                            const uint16_t h = bf16_rne(x);
+                            const float r1 = x - bf16_to_f(h);
+                            const uint16_t m = bf16_rne(r1);
+                            const float r2 = r1 - bf16_to_f(m);
+                            const uint16_t l = bf16_rne(r2);
+                            const int us = u ^ ((j >> 2) & 3);
+                            img[(size_t)(j * 12 + 0 + us) * 8 + e] = h;
+                            img[(size_t)(j * 12 + 4 + us) * 8 + e] = m;
+                            img[(size_t)(j * 12 + 8 + us) * 8 + e] = l;
+                        }
+            }
+}
+
+}  // namespace cddpm

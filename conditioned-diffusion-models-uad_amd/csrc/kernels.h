@@ -40,12 +40,19 @@ inline int conv_stat_records_up2(int H, int W) { return 8 * ((W / 2 + 31) / 32) 
 void launch_conv(const ConvArgs& a, hipStream_t stream);
 // wave-specialised persistent variant (conv_ws.hip); launch_conv forwards to it when CDDPM_CONV_WS=1 is set
 void launch_conv_ws(const ConvArgs& a, hipStream_t stream);
+// fp32-accurate variant on the bf16 matrix pipe (conv_x6.hip: operands split exactly into three bf16 terms, six
+// bf16 MFMAs per product group). Selected with CDDPM_CONV=x6 (default: the fp32-MFMA kernels of conv_mfma.hip). The
+// choice is made once per process and also selects the packed weight format (pack_conv_weights / packed_conv_floats).
+bool conv_x6_enabled();
+void launch_conv_x6(const ConvArgs& a, hipStream_t stream);
+void pack_conv_weights_x6(const float* w /*[Cout][Cin][k][k]*/, int Cout, int Cin, int taps, void* dst);
 
 // packed weight image sizes / packing (host side, cddpm_api.hip)
-// layout: [Cout/128][Cin/32][taps][128 rows x 8 slots of float4], slot s of row j stored at s ^ ((j>>1)&7)
+// fp32 layout: [Cout/128][Cin/32][taps][128 rows x 8 slots of float4], slot s of row j stored at s ^ ((j>>1)&7)
+// x6 layout  : [Cout/128][Cin/32][taps][128 rows x 12 slots of 8 bf16] (conv_x6.hip), 1.5 floats per weight
 size_t packed_conv_floats(int Cout, int Cin, int taps);
 void pack_conv_weights(const float* w /*[Cout][Cin][k][k]*/, int Cout, int Cin, int taps, float* dst);
-// folded weights of nearest-x2-upsample + 3x3: 4 parity classes x 4 taps, 16/9 of the original size
+// folded weights of nearest-x2-upsample + 3x3: 4 parity classes x 4 taps = 4 * packed_conv_floats(Cout, Cin, 4) floats
 void pack_conv_weights_up2(const float* w /*[Cout][Cin][3][3]*/, int Cout, int Cin, float* dst);
 
 // ------------------------------------------------------------------------------------------------
