@@ -67,6 +67,10 @@ __global__ __launch_bounds__(64 * ROWS) void conv_x6_kernel(const ConvArgs a) {
     constexpr int PH = UP2 ? ROWS + 1 : ROWS + 2 * PAD; // patch height (pixels)
     constexpr int NPIX = PW * PH;                       // 340 | 256 | 297 at ROWS = 8
     constexpr int NK = (NPIX * 8 + THREADS - 1) / THREADS;   // 16-B (4-channel) patch entries per thread: 6 | 4 | 5
+#ifndef CDDPM_X6_FOLD
+#define CDDPM_X6_FOLD 3
+#endif
+    constexpr int FOLD = (TAPS == 9) ? CDDPM_X6_FOLD : (TAPS == 4 ? 2 : 1);   // taps per accumulation group
     constexpr int WSLOTS = 128 * 12;                    // 16-B slots of a weight slab
     constexpr int WK = WSLOTS / THREADS;                // per thread: 3
     static_assert(WSLOTS % THREADS == 0, "weight slab must divide evenly");
@@ -186,7 +190,6 @@ __global__ __launch_bounds__(64 * ROWS) void conv_x6_kernel(const ConvArgs a) {
         }
     };
 
-    // Two-level accumulation as in conv_mfma.hip: `acc` collects one 32-channel chunk, `tot` sums the chunks.
     f32x16 acc[2][2], tot[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -210,7 +213,15 @@ __global__ __launch_bounds__(64 * ROWS) void conv_x6_kernel(const ConvArgs a) {
     acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[1], B[0], acc[1][0], 0, 0, 0);                   \
     acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[1], B[1], acc[1][1], 0, 0, 0);
 
-    auto compute = [&](int tap, int buf) {
+#define X6_MFMA4Z(A, B)                                                                                    \
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0], B[0], zero16, 0, 0, 0);                      \
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0], B[1], zero16, 0, 0, 0);                      \
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[1], B[0], zero16, 0, 0, 0);                      \
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[1], B[1], zero16, 0, 0, 0);
+
+    // `first`: the accumulators restart here (C = 0 in the first MFMA of each tile, no register clearing)
+    auto compute = [&](int tap, int buf, bool first) {
+        const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         const int ky = (TAPS == 9) ? (tap / 3) : (UP2 ? (tap >> 1) : 0);
         const int kx = (TAPS == 9) ? (tap - 3 * ky) : (UP2 ? (tap & 1) : 0);
         int aoff[2], asw[2];
@@ -239,7 +250,7 @@ __global__ __launch_bounds__(64 * ROWS) void conv_x6_kernel(const ConvArgs a) {
             X6_MFMA4(am, bl)
             X6_MFMA4(al, bm)
 #endif
-            X6_MFMA4(al, bh)
+            if (jk == 0 && first) { X6_MFMA4Z(al, bh) } else { X6_MFMA4(al, bh) }
             X6_MFMA4(ah, bl)
             X6_MFMA4(am, bm)
             X6_MFMA4(am, bh)
@@ -279,19 +290,22 @@ __global__ __launch_bounds__(64 * ROWS) void conv_x6_kernel(const ConvArgs a) {
             for (int i = 0; i < WK; ++i) wreg[i] = pn[tid + THREADS * i];
             if (last_tap && chunk + 1 < nch) load_act(chunk + 1);
             __syncthreads();
-            compute(main_seg ? t : (TAPS / 2), buf);   // skip segment: centre tap
+            // accumulation in three levels: an MFMA sums 16 products, `acc` collects FOLD taps of a 32-channel chunk
+            // (<= 96 products per chain), `tot` sums those groups. The rounding noise of an fp32 chain grows with the
+            // magnitude of its partial sums, so short chains folded into a long-lived total keep it near the
+            // storage-rounding level (tools/ubench/bf16_split_accuracy.hip, tools/chain_noise.py).
+            compute(main_seg ? t : (TAPS / 2), buf, (t % FOLD) == 0);   // skip segment: centre tap
             buf ^= 1;
-        }
+            if ((t % FOLD) == FOLD - 1 || last_tap) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                tot[i][j] += acc[i][j];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+                    for (int j = 0; j < 2; ++j) tot[i][j] += acc[i][j];
             }
+        }
     }
 #undef X6_MFMA4
+#undef X6_MFMA4Z
 
     __syncthreads();   // every wave is done with the patch / weight buffers before they become transpose space
     // ---- epilogue: as conv_mfma.hip -- each wave transposes its 64 x 64 tile through a private 8-KB LDS region so
@@ -364,7 +378,7 @@ __global__ __launch_bounds__(64 * ROWS) void conv_x6_kernel(const ConvArgs a) {
 }
 
 bool conv_x6_enabled() {
-    static const bool on = [] { const char* e = getenv("CDDPM_CONV"); return e && strcmp(e, "x6") == 0; }();
+    static const bool on = [] { const char* e = getenv("CDDPM_CONV"); return !(e && strcmp(e, "f32") == 0); }();
     return on;
 }
 

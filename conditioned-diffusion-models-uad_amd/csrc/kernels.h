@@ -41,7 +41,7 @@ void launch_conv(const ConvArgs& a, hipStream_t stream);
 // wave-specialised persistent variant (conv_ws.hip); launch_conv forwards to it when CDDPM_CONV_WS=1 is set
 void launch_conv_ws(const ConvArgs& a, hipStream_t stream);
 // fp32-accurate variant on the bf16 matrix pipe (conv_x6.hip: operands split exactly into three bf16 terms, six
-// bf16 MFMAs per product group). Selected with CDDPM_CONV=x6 (default: the fp32-MFMA kernels of conv_mfma.hip). The
+// bf16 MFMAs per product group). The default; CDDPM_CONV=f32 selects the fp32-MFMA kernels of conv_mfma.hip. The
 // choice is made once per process and also selects the packed weight format (pack_conv_weights / packed_conv_floats).
 bool conv_x6_enabled();
 void launch_conv_x6(const ConvArgs& a, hipStream_t stream);
