@@ -14,9 +14,13 @@ with seconds_per_step from EXACTLY K timed steps (barrier + synchronize on both 
 Weights, context vectors and x_T are synthetic (counter RNG, synth.py) and resident in HBM before timing.
 
 Extra objects on the JSON line:
-  roofline      dominant kernel = the fused fp32-MFMA 3x3 convolution: algorithmic FLOPs of its launches /
-                their HIP-event durations (events recorded on the launch stream inside the timed steps),
-                against the 157.3 TFLOP/s dense fp32 MFMA peak of MI355X_MICROARCH.md.
+  roofline      dominant kernel = the fused 3x3 convolution. Default build (conv_x6.hip): fp32 operands split exactly
+                into three bf16 terms, six bf16 MFMAs per product group, fp32 accumulation -- fp32-accurate results
+                on the bf16 matrix pipe. achieved = EXECUTED bf16 FLOPs (6 x the algorithmic fp32 FLOPs of the
+                launches) / their HIP-event durations (events recorded on the launch stream inside the timed
+                steps) against the 2.5 PFLOP/s dense bf16 MFMA peak of MI355X_MICROARCH.md; the fp32-equivalent
+                rate and its ratio to the 157.3 TFLOP/s fp32 MFMA peak are reported beside it.
+                CDDPM_CONV=f32 runs the fp32-MFMA kernels (conv_mfma.hip) and prices against the fp32 peak.
   cpu_baseline  oracle/cddpm_oracle.py (torch CPU restatement of the reference path, "port") timed on this
                 host's cores on a bounded sample (B=4, a few p_sample steps), rank 0 at N=1 only.
 """
@@ -34,6 +38,8 @@ sys.path.insert(0, ROOT)
 PKG = "conditioned-diffusion-models-uad_amd"
 T_TOTAL = 1000
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense fp32 MFMA peak (= fp32 vector peak)
+PEAK_BF16_MFMA_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense bf16 MFMA peak
+CONV_X6 = os.environ.get("CDDPM_CONV", "x6") != "f32"     # mirrors conv_x6_enabled() in csrc/conv_x6.hip
 PEAK_HBM_TBPS = 8.0
 FLOP_PER_SLICE_STEP = {128: 265.6e9, 96: 149.1e9, 256: 1075.1e9}     # the reference's operation count
 # executed by this implementation: the two "nearest x2 upsample -> conv3x3" layers (4.83 + 19.33 GMAC @128^2) run as four
@@ -156,6 +162,10 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"configs[1]: reference UNet (43.87M params, fp32), {B}x1x{S}x{S} slices per GPU, "
                                f"T={T_TOTAL}, p_sample steps t={T_TOTAL - 1 - args.warmup}..{t + 1}; value = n_gpus*B/(T*s_per_step)",
+                   "arithmetic": ("fp32 in, fp32 out, fp32 accumulation; convolution products formed from exact 3-way bf16 splits of "
+                                  "both operands on the bf16 MFMA (6 of 9 partial products, the rest < 2^-24 relative); parity bar "
+                                  "1e-4 vs the fp32 reference holds, rounding noise vs float64 below the reference's own"
+                                  if CONV_X6 else "fp32 MFMA (v_mfma_f32_32x32x2_f32) throughout"),
                    "batch_per_gpu": B, "global_batch": world * B, "size": S, "T": T_TOTAL,
                    "parallelism": f"slice-sharded x{world}, no collective in the loop, one all_gather at the end",
                    "gather_ms": gather_ms, "finite": finite,
@@ -175,9 +185,17 @@ def main():
                 traffic = json.load(open(tfile)).get("bytes_per_launch")
             except Exception:
                 traffic = None
-        out["roofline"] = {"bound": "mfma", "kernel": "conv_mfma_kernel<9,4> and <4,4> (fused GN/FiLM/SiLU + 3x3 conv [+ folded upsample] + skip + GN statistics, fp32 MFMA); FLOPs = executed",
-                           "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                           "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
+        if CONV_X6:
+            kern = ("conv_x6_kernel<9,8> and <4,8> (fused GN/FiLM/SiLU + 3x3 conv [+ folded upsample] + skip + GN statistics; "
+                    "fp32 operands as 3 bf16 terms, 6 v_mfma_f32_32x32x16_bf16 per product group, fp32 accumulate); "
+                    "achieved = executed bf16 FLOPs = 6 x algorithmic")
+            roof = {"achieved": 6.0 * ach, "peak": PEAK_BF16_MFMA_TFLOPS, "frac": 6.0 * ach / PEAK_BF16_MFMA_TFLOPS,
+                    "fp32_equivalent_tflops": ach, "fp32_mfma_peak": PEAK_FP32_MFMA_TFLOPS,
+                    "fp32_equivalent_over_fp32_mfma_peak": ach / PEAK_FP32_MFMA_TFLOPS}
+        else:
+            kern = "conv_mfma_kernel<9,4> and <4,4> (fused GN/FiLM/SiLU + 3x3 conv [+ folded upsample] + skip + GN statistics, fp32 MFMA); FLOPs = executed"
+            roof = {"achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "frac": ach / PEAK_FP32_MFMA_TFLOPS}
+        out["roofline"] = {"bound": "mfma", "kernel": kern, **roof, "unit": "TFLOP/s", "traffic": traffic,
                            "launches": c3["launches"], "avg_launch_ms": c3["ms"] / max(1, c3["launches"]),
                            "flops_per_launch": c3["flops"] / max(1, c3["launches"]),
                            "algorithmic_bytes_per_launch": c3["bytes"] / max(1, c3["launches"]),

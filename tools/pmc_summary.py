@@ -1,10 +1,11 @@
 #!/usr/bin/env python3
-"""Summarise the rocprofv3 --pmc passes of tools/pmc_passes.sh for the dominant kernel (conv_mfma_kernel<9,...>).
+"""Summarise the rocprofv3 --pmc passes of tools/pmc_passes.sh for the dominant kernel (default conv_x6_kernel<9,...>;
+third argument = another kernel-name substring, e.g. "conv_mfma_kernel<9" for CDDPM_CONV=f32 runs).
 
 Applies the gfx950 corrections of MI355X_MICROARCH.md: FETCH_SIZE (KB) under-reports wide (16 B/lane) coalesced
 reads by exactly 2x -> doubled; WRITE_SIZE (KB) is exact for 16-B-per-lane stores. Writes
 profiles/conv3x3_hbm_traffic.json (read by bench.py for roofline.traffic) and prints the utilisation figures.
-usage: python tools/pmc_summary.py gpurun_out profiles/r01_pmc_summary.json"""
+usage: python tools/pmc_summary.py gpurun_out profiles/r01_pmc_summary.json [kernel-substring]"""
 import collections
 import csv
 import json
@@ -12,7 +13,7 @@ import os
 import sys
 
 root, out = sys.argv[1], sys.argv[2]
-KEY = "conv_mfma_kernel<9"
+KEY = sys.argv[3] if len(sys.argv) > 3 else "conv_x6_kernel<9"
 
 
 def load(tag):
@@ -35,6 +36,7 @@ gui = tot(a, "GRBM_GUI_ACTIVE") / 8.0                 # summed over 8 XCDs
 res["launches"] = n
 res["avg_launch_us"] = ns / n / 1e3
 res["effective_clock_GHz"] = gui / ns
+res["kernel"] = KEY
 res["mfma_pipe_busy_frac"] = tot(a, "SQ_VALU_MFMA_BUSY_CYCLES") / (1024.0 * gui)   # 256 CUs x 4 SIMDs
 res["wave_cycles_split"] = {k: tot(a, k) / tot(a, "SQ_WAVE_CYCLES") for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY")}
 b = load("SQ_LDS_BANK_CONFLICT")
