@@ -44,7 +44,9 @@ def build_lib(force: bool = False, verbose: bool = False, defines=(), tag: str =
 
     def compile_one(src):
         obj = os.path.join(CSRC, src.replace(".hip", f"{('_' + tag) if tag else ''}.o"))
-        path = conv_src if (conv_src and src == "conv_mfma.hip") else os.path.join(CSRC, src)   # A/B of older conv kernels
+        # A/B of older conv kernels: an alternative file replaces conv_x6.hip if its name starts with conv_x6, else conv_mfma.hip
+        swap = "conv_x6.hip" if os.path.basename(conv_src).startswith("conv_x6") else "conv_mfma.hip"
+        path = conv_src if (conv_src and src == swap) else os.path.join(CSRC, src)
         cmd = [hipcc, *flags, f"-I{CSRC}", "-c", path, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:

@@ -1104,6 +1104,17 @@ int cddpm_op_gn_coef(cddpm_handle h, const float* src0, int C0, const float* src
     return 0;
 }
 
+size_t cddpm_packed_conv_bytes(int Cout, int Cin, int taps) {
+    if (Cout <= 0 || Cin <= 0 || Cout % 128 || Cin % 32 || (taps != 1 && taps != 9)) return 0;
+    return packed_conv_floats(Cout, Cin, taps) * sizeof(float);
+}
+
+int cddpm_pack_conv_weights(const float* w_host, int Cout, int Cin, int taps, void* dst_host) {
+    if (!w_host || !dst_host || cddpm_packed_conv_bytes(Cout, Cin, taps) == 0) return -1;
+    pack_conv_weights(w_host, Cout, Cin, taps, static_cast<float*>(dst_host));
+    return conv_x6_enabled() ? 1 : 0;
+}
+
 int cddpm_op_attention(cddpm_handle h, const float* qkv_dev, float* out_dev, int B, int N, int C, void* stream) {
     if (!h) return -1;
     if (C % 64 || N < 1) return fail(h, "cddpm_op_attention: C must be a multiple of 64");

@@ -37,6 +37,14 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
+#ifdef CDDPM_STAMPS
+// phase accounting for diagnostic builds: 0 prologue, 1 patch stage (barrier + transform + split + ds_write), 2 weight
+// stage (ds_write + prefetch issue + barrier), 3 MFMA compute, 4 fold, 5 epilogue
+#define STAMP(i) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); st_[i] += now_ - last_; last_ = now_; }
+#else
+#define STAMP(i)
+#endif
+
 __device__ __forceinline__ float silu_x6(float v) {
     // identical evaluation to conv_mfma.hip::silu_f (split-product exp2, ~1.5 ulp)
     const float t = fminf(-v * 1.44269502162933349609375f, 126.0f);
@@ -83,6 +91,11 @@ __global__ __launch_bounds__(64 * ROWS) void conv_x6_kernel(const ConvArgs a) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
+#ifdef CDDPM_STAMPS
+    unsigned long long st_[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long last_ = __builtin_amdgcn_s_memtime();
+    const unsigned long long t0c_ = last_, t0r_ = __builtin_amdgcn_s_memrealtime();
+#endif
     const int li = lane & 31;
     const int lh = lane >> 5;
     const int wm = wave % (ROWS / 2);   // pixel rows {2 wm, 2 wm + 1} of the tile
@@ -276,11 +289,13 @@ __global__ __launch_bounds__(64 * ROWS) void conv_x6_kernel(const ConvArgs a) {
         }
     }
     int buf = 0;
+    STAMP(0)
     for (int chunk = 0; chunk < nch; ++chunk) {
         const bool main_seg = chunk < nch_main;
         const int ntap = main_seg ? TAPS : 1;
         __syncthreads();   // every wave is done reading the previous patch
         store_act(chunk);
+        STAMP(1)
         for (int t = 0; t < ntap; ++t) {
 #pragma unroll
             for (int i = 0; i < WK; ++i) ldsW[buf * WSLOTS + tid + THREADS * i] = wreg[i];
@@ -290,17 +305,20 @@ __global__ __launch_bounds__(64 * ROWS) void conv_x6_kernel(const ConvArgs a) {
             for (int i = 0; i < WK; ++i) wreg[i] = pn[tid + THREADS * i];
             if (last_tap && chunk + 1 < nch) load_act(chunk + 1);
             __syncthreads();
+            STAMP(2)
             // accumulation in three levels: an MFMA sums 16 products, `acc` collects FOLD taps of a 32-channel chunk
             // (<= 96 products per chain), `tot` sums those groups. The rounding noise of an fp32 chain grows with the
             // magnitude of its partial sums, so short chains folded into a long-lived total keep it near the
             // storage-rounding level (tools/ubench/bf16_split_accuracy.hip, tools/chain_noise.py).
             compute(main_seg ? t : (TAPS / 2), buf, (t % FOLD) == 0);   // skip segment: centre tap
             buf ^= 1;
+            STAMP(3)
             if ((t % FOLD) == FOLD - 1 || last_tap) {
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j) tot[i][j] += acc[i][j];
+                STAMP(4)
             }
         }
     }
@@ -375,6 +393,16 @@ __global__ __launch_bounds__(64 * ROWS) void conv_x6_kernel(const ConvArgs a) {
             __builtin_amdgcn_wave_barrier();
         }
     }
+#ifdef CDDPM_STAMPS
+    STAMP(5)
+    if (a.stamps && lane == 0 && wave < 4) {
+        for (int i = 0; i < 6; ++i) atomicAdd(&a.stamps[wave * 8 + i], st_[i]);
+        if (wave == 0) {
+            atomicAdd(&a.stamps[40], __builtin_amdgcn_s_memtime() - t0c_);
+            atomicAdd(&a.stamps[41], __builtin_amdgcn_s_memrealtime() - t0r_);
+        }
+    }
+#endif
 }
 
 bool conv_x6_enabled() {

@@ -140,6 +140,53 @@ def test_library_exports_every_declared_symbol():
     assert b"model_channels" in lib.cddpm_last_error(None)
 
 
+def _bf16_rne(x: np.ndarray) -> np.ndarray:
+    """float32 -> bf16 (round to nearest even), returned as float32"""
+    u = x.astype(np.float32).view(np.uint32).astype(np.uint64)
+    u = (u + 0x7FFF + ((u >> 16) & 1)) >> 16
+    return (u.astype(np.uint32) << 16).view(np.float32)
+
+
+def test_bf16_split_weight_image_is_exact():
+    """The convolution forms fp32 products from three bf16 terms per operand (conv_x6.hip); the whole parity claim
+    rests on hi + mid + lo == w EXACTLY. Checked on the host packer through the C ABI (no GPU), together with the
+    documented image layout (include/cddpm.h)."""
+    lib = load_pkg("_lib").load_library()
+    Cout, Cin, taps = 128, 64, 9
+    rng = np.random.default_rng(0)
+    w = (rng.standard_normal((Cout, Cin, 3, 3)) * 0.05).astype(np.float32)
+    w.flat[:10] = [0.0, -0.0, 1.0, -1.0, 3.0e-20, 65280.0, 1.0 + 2.0 ** -23, -(2.0 ** -100), 0.1, 1.0 - 2.0 ** -24]
+    n = lib.cddpm_packed_conv_bytes(Cout, Cin, taps)
+    assert lib.cddpm_packed_conv_bytes(100, Cin, taps) == 0 and lib.cddpm_packed_conv_bytes(Cout, Cin, 4) == 0
+    buf = (ctypes.c_uint8 * n)()
+    fmt = lib.cddpm_pack_conv_weights(w.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), Cout, Cin, taps, buf)
+    assert fmt in (0, 1)
+    wt = w.reshape(Cout, Cin, taps)
+    if fmt == 0:                                    # fp32-MFMA image (CDDPM_CONV=f32)
+        assert n == w.size * 4
+        img = np.frombuffer(buf, np.float32).reshape(Cin // 32, taps, 128, 8, 4)
+        for j in (0, 1, 2, 77, 127):
+            for sl in range(8):
+                got = img[:, :, j, sl ^ ((j >> 1) & 7), :]                      # [chunk][tap][4 channels]
+                want = wt[j].reshape(Cin // 32, 8, 4, taps)[:, sl].transpose(0, 2, 1)
+                assert np.array_equal(got, want)
+        return
+    assert n == w.size * 6
+    img = np.frombuffer(buf, np.uint16).reshape(Cin // 32, taps, 128, 12, 8)
+    parts = np.zeros((3, Cout, Cin, taps), np.float32)
+    for j in range(128):
+        key = (j >> 2) & 3
+        for s in range(3):
+            for u in range(4):
+                v = (img[:, :, j, 4 * s + (u ^ key), :].astype(np.uint32) << 16).view(np.float32)   # [chunk][tap][8]
+                parts[s, j].reshape(Cin // 32, 4, 8, taps)[:, u] = v.transpose(0, 2, 1)
+    hi, mid, lo = parts.astype(np.float64)
+    assert np.array_equal(hi + mid + lo, wt.astype(np.float64)), "three-term bf16 split must reproduce every weight exactly"
+    assert np.array_equal(parts[0], _bf16_rne(wt))                              # hi = bf16(w), round to nearest even
+    assert np.array_equal(parts[1], _bf16_rne(wt - parts[0]))                   # mid = bf16(w - hi)
+    assert (np.abs(mid) <= np.abs(hi) * 2.0 ** -8 + 1e-45).all() and (np.abs(lo) <= np.abs(hi) * 2.0 ** -16 + 1e-45).all()
+
+
 @pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
 def test_engine_fails_loudly_without_gpu():
     eng = load_pkg("engine")
