@@ -38,8 +38,8 @@ sys.path.insert(0, ROOT)
 PKG = "conditioned-diffusion-models-uad_amd"
 T_TOTAL = 1000
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense fp32 MFMA peak (= fp32 vector peak)
-PEAK_BF16_MFMA_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense bf16 MFMA peak
-CONV_X6 = os.environ.get("CDDPM_CONV", "x6") != "f32"     # mirrors conv_x6_enabled() in csrc/conv_x6.hip
+PEAK_BF16_MFMA_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense bf16 / fp16 MFMA peak
+CONV_MODE = {"f32": "f32", "x6": "x6"}.get(os.environ.get("CDDPM_CONV", ""), "h3")     # mirrors conv_mode() in csrc/conv_x6.hip
 PEAK_HBM_TBPS = 8.0
 FLOP_PER_SLICE_STEP = {128: 265.6e9, 96: 149.1e9, 256: 1075.1e9}     # the reference's operation count
 # executed by this implementation: the two "nearest x2 upsample -> conv3x3" layers (4.83 + 19.33 GMAC @128^2) run as four
@@ -162,10 +162,13 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"configs[1]: reference UNet (43.87M params, fp32), {B}x1x{S}x{S} slices per GPU, "
                                f"T={T_TOTAL}, p_sample steps t={T_TOTAL - 1 - args.warmup}..{t + 1}; value = n_gpus*B/(T*s_per_step)",
-                   "arithmetic": ("fp32 in, fp32 out, fp32 accumulation; convolution products formed from exact 3-way bf16 splits of "
-                                  "both operands on the bf16 MFMA (6 of 9 partial products, the rest < 2^-24 relative); parity bar "
-                                  "1e-4 vs the fp32 reference holds, rounding noise vs float64 below the reference's own"
-                                  if CONV_X6 else "fp32 MFMA (v_mfma_f32_32x32x2_f32) throughout"),
+                   "arithmetic": {"h3": "fp32 in, fp32 out, fp32 accumulation; convolution products formed from two-term fp16 splits of both "
+                                        "operands (|x - hi - mid| <= 2^-23 |x|, rms 0.73 x 2^-24; weights pre-scaled by a power of two) on the fp16 MFMA, 3 of 4 "
+                                        "partial products (the 4th < 2^-24 relative); parity bar 1e-4 vs the fp32 reference holds, rounding "
+                                        "noise vs float64 below the reference's own",
+                                  "x6": "fp32 in, fp32 out, fp32 accumulation; convolution products formed from exact 3-way bf16 splits of "
+                                        "both operands on the bf16 MFMA (6 of 9 partial products, the rest < 2^-24 relative)",
+                                  "f32": "fp32 MFMA (v_mfma_f32_32x32x2_f32) throughout"}[CONV_MODE],
                    "batch_per_gpu": B, "global_batch": world * B, "size": S, "T": T_TOTAL,
                    "parallelism": f"slice-sharded x{world}, no collective in the loop, one all_gather at the end",
                    "gather_ms": gather_ms, "finite": finite,
@@ -185,11 +188,13 @@ def main():
                 traffic = json.load(open(tfile)).get("bytes_per_launch")
             except Exception:
                 traffic = None
-        if CONV_X6:
-            kern = ("conv_x6_kernel<9,8> and <4,8> (fused GN/FiLM/SiLU + 3x3 conv [+ folded upsample] + skip + GN statistics; "
-                    "fp32 operands as 3 bf16 terms, 6 v_mfma_f32_32x32x16_bf16 per product group, fp32 accumulate); "
-                    "achieved = executed bf16 FLOPs = 6 x algorithmic")
-            roof = {"achieved": 6.0 * ach, "peak": PEAK_BF16_MFMA_TFLOPS, "frac": 6.0 * ach / PEAK_BF16_MFMA_TFLOPS,
+        if CONV_MODE != "f32":
+            nprod = 3.0 if CONV_MODE == "h3" else 6.0
+            kern = ("conv_split_kernel<9,8,%d> and <4,8,%d> (fused GN/FiLM/SiLU + 3x3 conv [+ folded upsample] + skip + GN statistics; "
+                    "fp32 operands as %s, %d %s per product group, fp32 accumulate); achieved = executed 16-bit-pipe FLOPs = %d x algorithmic"
+                    % ((2, 2, "2 fp16 terms", 3, "v_mfma_f32_32x32x16_f16", 3) if CONV_MODE == "h3"
+                       else (3, 3, "3 bf16 terms", 6, "v_mfma_f32_32x32x16_bf16", 6)))
+            roof = {"achieved": nprod * ach, "peak": PEAK_BF16_MFMA_TFLOPS, "frac": nprod * ach / PEAK_BF16_MFMA_TFLOPS,
                     "fp32_equivalent_tflops": ach, "fp32_mfma_peak": PEAK_FP32_MFMA_TFLOPS,
                     "fp32_equivalent_over_fp32_mfma_peak": ach / PEAK_FP32_MFMA_TFLOPS}
         else:

@@ -66,7 +66,7 @@ SYMBOLS = {
     "cddpm_op_gn_coef": (_i, [_vp, _fp, _i, _fp, _i, _fp, _fp, _fp, _fp, _i, _i, _vp]),
     "cddpm_op_attention": (_i, [_vp, _fp, _fp, _i, _i, _i, _vp]),
     "cddpm_packed_conv_bytes": (_sz, [_i, _i, _i]),
-    "cddpm_pack_conv_weights": (_i, [_fp, _i, _i, _i, _vp]),
+    "cddpm_pack_conv_weights": (_i, [_fp, _i, _i, _i, _vp, C.POINTER(_i)]),
 }
 
 _lib = None

@@ -22,7 +22,7 @@ using namespace cddpm;
 
 namespace {
 
-struct ConvW { float* wpk = nullptr; float* bias = nullptr; int Cin = 0, Cout = 0, taps = 0; };
+struct ConvW { float* wpk = nullptr; float* bias = nullptr; int Cin = 0, Cout = 0, taps = 0; int wexp = 0; };   // wexp: fp16-split pre-scale exponent
 struct NormW { float* gamma = nullptr; float* beta = nullptr; int C = 0; };
 
 struct ResW {
@@ -448,11 +448,14 @@ int upload_norm(cddpm_ctx* h, const HostWeights& hw, const std::string& p, int C
     return upload(h, &n->beta, hw.get(p + ".bias"), C);
 }
 
+// wexp < 0: choose the pre-scale exponent from this tensor; >= 0: imposed (tensors accumulated into one output tile share it)
 int upload_conv(cddpm_ctx* h, const HostWeights& hw, const std::string& p, int Cin, int Cout, int taps, ConvW* c,
-                bool with_bias = true) {
+                bool with_bias = true, int wexp = -1) {
     c->Cin = Cin; c->Cout = Cout; c->taps = taps;
+    const float* w = hw.get(p + ".weight");
+    c->wexp = wexp >= 0 ? wexp : conv_weight_exp(w, (size_t)Cout * Cin * taps);
     std::vector<float> pk(packed_conv_floats(Cout, Cin, taps));
-    pack_conv_weights(hw.get(p + ".weight"), Cout, Cin, taps, pk.data());
+    pack_conv_weights(w, Cout, Cin, taps, pk.data(), c->wexp);
     if (upload(h, &c->wpk, pk.data(), pk.size())) return -1;
     if (with_bias) return upload(h, &c->bias, hw.get(p + ".bias"), Cout);
     return 0;
@@ -494,6 +497,7 @@ void run_res(cddpm_ctx* h, const ResW& r, const float* x0, int C0, const float* 
     ConvArgs a;
     zero_conv_args(a);
     a.B = B; a.Cout = r.Cout; a.taps = 9; a.wpk = r.conv1.wpk; a.bias = r.conv1.bias; a.out = h->bufH;
+    a.wscale_inv = ldexpf(1.0f, -r.conv1.wexp);
     int Ho = H, Wo = W;
     const float* resid = x0;
     int res_up = 0;
@@ -521,7 +525,7 @@ void run_res(cddpm_ctx* h, const ResW& r, const float* x0, int C0, const float* 
     zero_conv_args(c);
     c.B = B; c.H = Ho; c.W = Wo; c.Cout = r.Cout; c.taps = 9;
     c.src0 = h->bufH; c.C0 = r.Cout; c.srcH = Ho; c.srcW = Wo; c.coef = h->coef; c.silu = 1;
-    c.wpk = r.conv2.wpk; c.bias = r.bias2; c.out = dst;
+    c.wpk = r.conv2.wpk; c.bias = r.bias2; c.out = dst; c.wscale_inv = ldexpf(1.0f, -r.conv2.wexp);
     if (r.has_skip) {
         c.skip0 = x0; c.S0 = C0; c.skip1 = x1; c.S1 = C1; c.skip_wpk = r.skip.wpk;
     } else {
@@ -538,7 +542,7 @@ void run_attn(cddpm_ctx* h, const AttnW& w, const float* x, float* dst, int B, i
     zero_conv_args(a);
     a.B = B; a.H = H; a.W = W; a.Cout = 3 * w.C; a.taps = 1;
     a.src0 = x; a.C0 = w.C; a.srcH = H; a.srcW = W; a.coef = h->coef; a.silu = 0;
-    a.wpk = w.qkv.wpk; a.bias = w.qkv.bias; a.out = h->qkvbuf;
+    a.wpk = w.qkv.wpk; a.bias = w.qkv.bias; a.out = h->qkvbuf; a.wscale_inv = ldexpf(1.0f, -w.qkv.wexp);
     conv_launch(h, a, s);
     {
         Prof pa(h, PC_ATTN, 4.0 * B * (double)N * N * w.C, 4.0 * B * (double)N * 4 * w.C, s);
@@ -548,7 +552,7 @@ void run_attn(cddpm_ctx* h, const AttnW& w, const float* x, float* dst, int B, i
     zero_conv_args(p);
     p.B = B; p.H = H; p.W = W; p.Cout = w.C; p.taps = 1;
     p.src0 = h->attbuf; p.C0 = w.C; p.srcH = H; p.srcW = W;
-    p.wpk = w.proj.wpk; p.bias = w.proj.bias; p.res = x; p.out = dst;
+    p.wpk = w.proj.wpk; p.bias = w.proj.bias; p.res = x; p.out = dst; p.wscale_inv = ldexpf(1.0f, -w.proj.wexp);
     conv_launch(h, p, s);
 }
 
@@ -753,15 +757,18 @@ int cddpm_load_weights(cddpm_handle h, const char* const* names, const float* co
             // evaluated as four 2x2-tap convolutions of the low-resolution input (4/9 of the multiplies)
             r.conv1.Cin = r.Cin; r.conv1.Cout = r.Cout; r.conv1.taps = 4;
             std::vector<float> pk(4 * packed_conv_floats(r.Cout, r.Cin, 4));
-            pack_conv_weights_up2(hw.get(r.prefix + ".in_layers.2.weight"), r.Cout, r.Cin, pk.data());
+            r.conv1.wexp = pack_conv_weights_up2(hw.get(r.prefix + ".in_layers.2.weight"), r.Cout, r.Cin, pk.data());
             if (upload(h, &r.conv1_up2, pk.data(), pk.size())) return -1;
             if (upload(h, &r.conv1.bias, hw.get(r.prefix + ".in_layers.2.bias"), r.Cout)) return -1;
         } else if (upload_conv(h, hw, r.prefix + ".in_layers.2", r.Cin, r.Cout, 9, &r.conv1)) return -1;
         if (upload_norm(h, hw, r.prefix + ".out_layers.0", r.Cout, &r.gn2)) return -1;
-        if (upload_conv(h, hw, r.prefix + ".out_layers.3", r.Cout, r.Cout, 9, &r.conv2, false)) return -1;
+        // conv2 and the fused 1x1 skip_connection accumulate into the same tile: one pre-scale exponent for both
+        int e2 = conv_weight_exp(hw.get(r.prefix + ".out_layers.3.weight"), (size_t)r.Cout * r.Cout * 9);
+        if (r.has_skip) e2 = std::min(e2, conv_weight_exp(hw.get(r.prefix + ".skip_connection.weight"), (size_t)r.Cout * r.Cin));
+        if (upload_conv(h, hw, r.prefix + ".out_layers.3", r.Cout, r.Cout, 9, &r.conv2, false, e2)) return -1;
         std::vector<float> b2(hw.get(r.prefix + ".out_layers.3.bias"), hw.get(r.prefix + ".out_layers.3.bias") + r.Cout);
         if (r.has_skip) {
-            if (upload_conv(h, hw, r.prefix + ".skip_connection", r.Cin, r.Cout, 1, &r.skip, false)) return -1;
+            if (upload_conv(h, hw, r.prefix + ".skip_connection", r.Cin, r.Cout, 1, &r.skip, false, e2)) return -1;
             const float* bs = hw.get(r.prefix + ".skip_connection.bias");
             for (int i = 0; i < r.Cout; ++i) b2[i] += bs[i];
         }
@@ -984,8 +991,9 @@ int cddpm_op_conv(cddpm_handle h, const float* src0, int C0, const float* src1, 
     hipStream_t s = (hipStream_t)stream;
     HIPCHECK(h, hipSetDevice(h->device));
     std::vector<float> pk(folded ? 4 * packed_conv_floats(Cout, Cin, 4) : packed_conv_floats(Cout, Cin, taps));
-    if (folded) pack_conv_weights_up2(w_host, Cout, Cin, pk.data());
-    else pack_conv_weights(w_host, Cout, Cin, taps, pk.data());
+    int wexp = 0;
+    if (folded) wexp = pack_conv_weights_up2(w_host, Cout, Cin, pk.data());
+    else { wexp = conv_weight_exp(w_host, (size_t)Cout * Cin * taps); pack_conv_weights(w_host, Cout, Cin, taps, pk.data(), wexp); }
     float *dw = nullptr, *db = nullptr;
     HIPCHECK(h, hipMalloc((void**)&dw, pk.size() * sizeof(float)));
     HIPCHECK(h, hipMalloc((void**)&db, (size_t)Cout * sizeof(float)));
@@ -996,6 +1004,7 @@ int cddpm_op_conv(cddpm_handle h, const float* src0, int C0, const float* src1, 
     a.src0 = src0; a.C0 = C0; a.src1 = src1; a.C1 = C1;
     a.srcH = upsample ? H / 2 : H; a.srcW = upsample ? W / 2 : W; a.upsample = folded ? 0 : upsample;
     a.coef = coef_dev; a.silu = silu; a.wpk = dw; a.bias = db; a.res = res_dev; a.res_up = res_upsample;
+    a.wscale_inv = ldexpf(1.0f, -wexp);
     a.out = out_dev; a.B = B; a.H = H; a.W = W; a.Cout = Cout; a.taps = folded ? 4 : taps;
     launch_conv(a, s);
     HIPCHECK(h, hipGetLastError());
@@ -1030,14 +1039,15 @@ int cddpm_op_conv_bench(cddpm_handle h, int C0, int C1, int Cout, int ksize, int
     };
     int rc = 0;
     rc |= alloc_fill(&x0, n0, 1, 1.f); rc |= alloc_fill(&x1, n1, 2, 1.f); rc |= alloc_fill(&sk, nsk, 3, 1.f);
-    // weights: random host values through the packer of the active kernel family (fp32 image or bf16 x 3 image)
+    // weights: random host values through the packer of the active kernel family (fp32 image or 16-bit split image)
+    const int bench_wexp = (conv_mode() == 2) ? 18 : 0;
     auto pack_upload = [&](float** p, int cin, int tp, uint64_t seed) -> int {
         if (!cin) return 0;
         std::vector<float> hwt((size_t)Cout * cin * tp);
         uint64_t st = seed;
         for (float& v : hwt) { st = st * 6364136223846793005ull + 1442695040888963407ull; v = ((int64_t)(st >> 33) - (1ll << 30)) * (0.05f / (1ll << 30)); }
         std::vector<float> pk(packed_conv_floats(Cout, cin, tp));
-        pack_conv_weights(hwt.data(), Cout, cin, tp, pk.data());
+        pack_conv_weights(hwt.data(), Cout, cin, tp, pk.data(), bench_wexp);      // |w| < 0.05 -> 2^18 keeps it below 2^14
         if (hipMalloc((void**)p, pk.size() * sizeof(float)) != hipSuccess) return -1;
         return hipMemcpy(*p, pk.data(), pk.size() * sizeof(float), hipMemcpyHostToDevice) == hipSuccess ? 0 : -1;
     };
@@ -1054,6 +1064,7 @@ int cddpm_op_conv_bench(cddpm_handle h, int C0, int C1, int Cout, int ksize, int
     a.coef = use_coef ? cf : nullptr; a.silu = silu; a.wpk = w; a.bias = bs; a.res = res; a.res_up = (res_mode == 2);
     a.out = out; a.B = B; a.H = H; a.W = W; a.Cout = Cout; a.taps = taps;
     a.skip0 = sk; a.S0 = skipC; a.skip_wpk = ws;
+    a.wscale_inv = ldexpf(1.0f, -bench_wexp);
     a.stamps = nullptr;
     hipEvent_t e0, e1;
     HIPCHECK(h, hipEventCreate(&e0));
@@ -1109,10 +1120,12 @@ size_t cddpm_packed_conv_bytes(int Cout, int Cin, int taps) {
     return packed_conv_floats(Cout, Cin, taps) * sizeof(float);
 }
 
-int cddpm_pack_conv_weights(const float* w_host, int Cout, int Cin, int taps, void* dst_host) {
+int cddpm_pack_conv_weights(const float* w_host, int Cout, int Cin, int taps, void* dst_host, int* scale_exp_out) {
     if (!w_host || !dst_host || cddpm_packed_conv_bytes(Cout, Cin, taps) == 0) return -1;
-    pack_conv_weights(w_host, Cout, Cin, taps, static_cast<float*>(dst_host));
-    return conv_x6_enabled() ? 1 : 0;
+    const int wexp = conv_weight_exp(w_host, (size_t)Cout * Cin * taps);
+    pack_conv_weights(w_host, Cout, Cin, taps, static_cast<float*>(dst_host), wexp);
+    if (scale_exp_out) *scale_exp_out = wexp;
+    return conv_mode();
 }
 
 int cddpm_op_attention(cddpm_handle h, const float* qkv_dev, float* out_dev, int B, int N, int C, void* stream) {

@@ -371,7 +371,7 @@ __global__ __launch_bounds__(64 * NWV, NWV / 2) void conv_mfma_kernel(const Conv
 }
 
 void launch_conv(const ConvArgs& a, hipStream_t stream) {
-    if (conv_x6_enabled()) { launch_conv_x6(a, stream); return; }
+    if (conv_mode() != 0) { launch_conv_split(a, stream); return; }
     static const bool use_ws = [] { const char* e = getenv("CDDPM_CONV_WS"); return e && e[0] == '1'; }();
     if (use_ws && a.taps != 4) { launch_conv_ws(a, stream); return; }
     // 4 waves (64 x 64 per wave, 2 waves per SIMD) is the default; CDDPM_CONV_WAVES=8 selects the 8-wave split
@@ -408,12 +408,12 @@ void launch_conv(const ConvArgs& a, hipStream_t stream) {
 
 size_t packed_conv_floats(int Cout, int Cin, int taps) {
     const size_t n = (size_t)Cout * Cin * taps;
-    return conv_x6_enabled() ? n + n / 2 : n;      // x6: three bf16 per weight
+    return conv_mode() == 1 ? n + n / 2 : n;      // x6: three bf16 per weight; h3: two fp16; f32: one float
 }
 
 // w: PyTorch [Cout][Cin][k][k] (taps = k*k, tap = ky*3+kx) -> [Cout/128][Cin/32][taps][128][8 slots][4]
-void pack_conv_weights(const float* w, int Cout, int Cin, int taps, float* dst) {
-    if (conv_x6_enabled()) { pack_conv_weights_x6(w, Cout, Cin, taps, dst); return; }
+void pack_conv_weights(const float* w, int Cout, int Cin, int taps, float* dst, int wexp) {
+    if (conv_mode() != 0) { pack_conv_weights_split(w, Cout, Cin, taps, dst, wexp); return; }
     const int ncb = Cout / 128, nch = Cin / 32;
     for (int cb = 0; cb < ncb; ++cb)
         for (int ch = 0; ch < nch; ++ch)
@@ -435,8 +435,10 @@ void pack_conv_weights(const float* w, int Cout, int Cin, int taps, float* dst) 
 //   rows  a = 0: ty 0 <- ky {0},    ty 1 <- ky {1, 2};   a = 1: ty 0 <- ky {0, 1}, ty 1 <- ky {2}   (columns alike)
 // dst: [4 classes][Cout/128][Cin/32][4 taps][image], each class packed like pack_conv_weights with taps = 4
 // (4 * packed_conv_floats(Cout, Cin, 4) floats).
-void pack_conv_weights_up2(const float* w /*[Cout][Cin][3][3]*/, int Cout, int Cin, float* dst) {
+int pack_conv_weights_up2(const float* w /*[Cout][Cin][3][3]*/, int Cout, int Cin, float* dst) {
     std::vector<float> wf((size_t)Cout * Cin * 4);
+    int wexp = 24;      // one exponent for the four classes: they share the bias / epilogue of one launch
+    for (int pass = 0; pass < 2; ++pass)
     for (int cls = 0; cls < 4; ++cls) {
         const int pa = cls >> 1, pb = cls & 1;
         for (size_t oc = 0; oc < (size_t)Cout * Cin; ++oc)
@@ -449,8 +451,10 @@ void pack_conv_weights_up2(const float* w /*[Cout][Cin][3][3]*/, int Cout, int C
                         for (int kx = kx0; kx <= kx1; ++kx) acc += (double)w[oc * 9 + ky * 3 + kx];
                     wf[oc * 4 + ty * 2 + tx] = (float)acc;
                 }
-        pack_conv_weights(wf.data(), Cout, Cin, 4, dst + (size_t)cls * packed_conv_floats(Cout, Cin, 4));
+        if (pass == 0) { const int e = conv_weight_exp(wf.data(), wf.size()); if (e < wexp) wexp = e; }
+        else pack_conv_weights(wf.data(), Cout, Cin, 4, dst + (size_t)cls * packed_conv_floats(Cout, Cin, 4), wexp);
     }
+    return wexp;
 }
 
 }  // namespace cddpm

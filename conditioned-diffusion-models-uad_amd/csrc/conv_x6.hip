@@ -1,28 +1,35 @@
-// Fused implicit-GEMM convolution for gfx950 (MI355X): fp32 accuracy on the bf16 matrix pipe.
+// Fused implicit-GEMM convolution for gfx950 (MI355X): fp32 accuracy on the 16-bit matrix pipe.
 //
 // Same operator as conv_mfma.hip (see there for what is fused and the reference lines it replaces:
 // src/models/modules/OpenAI_Unet.py:284-338, :386-394, :118-128, :948), same arguments, same results to fp32
-// rounding. What changes is how a product of two fp32 numbers reaches the accumulator:
+// rounding. What changes is how a product of two fp32 numbers reaches the accumulator: every fp32 operand is split
+// into a few 16-bit terms whose sum reproduces it to fp32 precision, the partial products are exact in fp32 and the
+// 16-bit MFMA (16x the rate of the fp32 MFMA: 2.5 PFLOP/s vs 157 TFLOP/s dense) accumulates them in fp32.
 //
-//   every fp32 operand is split EXACTLY into three bf16 terms, x = hi + mid + lo (round-to-nearest at each step:
-//   hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid); 3 x 8 significant bits cover fp32's 24), and
-//   a * b = hi*hi + hi*mid + mid*hi + mid*mid + hi*lo + lo*hi   (+ terms below 2^-24 |a b|, dropped).
-//   Each bf16 x bf16 product is exact in fp32 and v_mfma_f32_32x32x16_bf16 accumulates in fp32, so the six MFMAs
-//   carry the same information as one fp32 FMA chain -- measured against fp64 the result is slightly BETTER than
-//   the fp32 MFMA (v_mfma_f32_32x32x2_f32) path: rms error 2.9e-7 vs 3.2e-7 of rms(C) at K = 4608, both folded per
-//   32-channel chunk; tools/ubench/bf16_split_accuracy.hip. The bf16 pipe runs 16x the fp32 pipe's rate
-//   (2.5 PFLOP/s vs 157 TFLOP/s dense), so six bf16 MFMAs cost 6/16 of the fp32 MFMAs they replace.
+//   NS = 2, fp16 (default, CDDPM_CONV=h3):  hi = fp16(x), mid = fp16(x - hi), round-to-nearest: two 11-bit terms,
+//       |x - hi - mid| <= 2^-23 |x| (one fp32 ulp at worst; 75 % of fp32 values are reproduced exactly, rms error
+//       0.73 x 2^-24 |x|) while mid is a normal fp16, i.e. |x| >= 2^-2; below that the error is ABSOLUTE, <= 2^-25.
+//       a*b = hi*hi + hi*mid + mid*hi (+ mid*mid <= 2^-24 |ab|, dropped): 3 MFMAs
+//       (v_mfma_f32_32x32x16_f16) = 3/16 of the fp32-MFMA cost. fp16's exponent range needs care: weights are
+//       pre-scaled by a power of two chosen per convolution so that max|w| lands in [2^13, 2^14) (exact; the epilogue
+//       multiplies by the inverse), activations are used as they are -- after GroupNorm/FiLM/SiLU they are O(1), the
+//       domain is |act| < 65504 (beyond it fp16 overflows to inf and the result is NaN: loud, not silently wrong).
+//   NS = 3, bf16 (CDDPM_CONV=x6): hi, mid, lo = three 8-bit terms, exact over the whole fp32 range;
+//       a*b = hh + hm + mh + mm + hl + lh (+ terms <= 2^-24 |ab|): 6 MFMAs (v_mfma_f32_32x32x16_bf16) = 6/16.
+//
+// Against fp64 (tools/ubench/bf16_split_accuracy.hip, K = 4608, SiLU-distributed activations, folded every 96
+// products): fp16x3 1.9e-7, bf16x6 2.0e-7 of rms(C); the fp32 MFMA chain folded per 288: 3.2e-7; the reference's CPU
+// fmaf chain 1.2e-6. On the whole reverse chain the rounding noise against float64 is below the reference's own
+// (tools/chain_noise.py).
 //
 // GEMM view:  D[pixel][cout] = sum_{tap, ci} act(X)[pixel + tap][ci] * Wt[tap][ci][cout]
 //   M = 256 pixels (8 image rows x 32 columns), N = 128 output channels, K step = 32 input channels x 1 tap
 //   = 2 MFMA k-steps of 16. 8 waves (2 per SIMD), each owns 64 pixels x 64 couts = 2 x 2 MFMA tiles.
-// LDS (one workgroup per CU, <= 124 KB):
-//   act patch   : (8+2) x (32+2) pixels, per pixel 3 splits x 32 channels bf16 = 12 slots of 16 B;
-//                 slot (split s, u = channel / 8) stored at 4 s + (u ^ ((pixel >> 2) & 3))
-//   weight slab : 2 buffers x [128 cout][12 slots], same addressing; the packed global image (host-split weights,
-//                 pack_conv_weights_x6) IS the LDS image, so staging is a linear 16-B copy
-//   With a 12-slot pixel stride, 16 consecutive pixels x one slot cover all 16 four-bank groups: ds_read_b128 of a
-//   fragment is bank-conflict free.
+// LDS (one workgroup per CU): per pixel / per cout row SP = 4 NS slots of 16 B (slot = split s, u = channel / 8):
+//   NS = 3: stride 12 slots, slot (s, u) at 4 s + (u ^ ((row >> 2) & 3));  NS = 2: stride 8, (4 s + u) ^ ((row >> 1) & 7)
+//   -> 16 consecutive rows x one slot cover all 16 four-bank groups: ds_read_b128 of a fragment is conflict free.
+//   act patch (8+2) x (32+2) pixels (65 | 43.5 KB) + 2 weight slabs [128 cout][SP] (49 | 32 KB) + coefficient cache;
+//   the packed global weight image (host-split, pack_conv_weights_split) IS the LDS image: staging is a 16-B copy.
 // A lane's 16-B fragment = 8 consecutive channels = its K elements of one k-step (lane>>5 selects the half).
 #include "kernels.h"
 #include <cstdlib>
@@ -36,6 +43,18 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+template <int NS> struct SplitT;
+template <> struct SplitT<3> {
+    typedef bf16x8 v8; typedef bf16x4 v4;
+    static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+};
+template <> struct SplitT<2> {
+    typedef f16x8 v8; typedef f16x4 v4;
+    static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+};
 
 #ifdef CDDPM_STAMPS
 // phase accounting for diagnostic builds: 0 prologue, 1 patch stage (barrier + transform + split + ds_write), 2 weight
@@ -56,17 +75,22 @@ __device__ __forceinline__ float silu_x6(float v) {
     return v * __builtin_amdgcn_rcpf(1.0f + e);
 }
 
-// exact three-way split of four fp32 values into bf16 quads (8 B each)
-__device__ __forceinline__ void split3x4(const v4f v, bf16x4& h, bf16x4& m, bf16x4& l) {
-    h = __builtin_convertvector(v, bf16x4);
-    const v4f r1 = v - __builtin_convertvector(h, v4f);
-    m = __builtin_convertvector(r1, bf16x4);
-    const v4f r2 = r1 - __builtin_convertvector(m, v4f);
-    l = __builtin_convertvector(r2, bf16x4);
+// split of four fp32 values into NS 16-bit quads (8 B each): t[0] = cvt(v), t[1] = cvt(v - t[0]), ...
+template <int NS>
+__device__ __forceinline__ void split_x4(const v4f v, typename SplitT<NS>::v4 (&t)[NS]) {
+    typedef typename SplitT<NS>::v4 q4;
+    v4f r = v;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        t[s] = __builtin_convertvector(r, q4);
+        r = r - __builtin_convertvector(t[s], v4f);
+    }
 }
 
-template <int TAPS, int ROWS>
-__global__ __launch_bounds__(64 * ROWS) void conv_x6_kernel(const ConvArgs a) {
+template <int TAPS, int ROWS, int NS>
+__global__ __launch_bounds__(64 * ROWS) void conv_split_kernel(const ConvArgs a) {
+    typedef typename SplitT<NS>::v8 frag;
+    constexpr int SP = 4 * NS;                          // 16-B slots per pixel / per cout row
     constexpr int THREADS = 64 * ROWS;
     // TAPS == 4: folded "nearest x2 upsample -> 3x3 conv", one parity class of the output per tile (see conv_mfma.hip)
     constexpr bool UP2 = (TAPS == 4);
@@ -79,13 +103,13 @@ __global__ __launch_bounds__(64 * ROWS) void conv_x6_kernel(const ConvArgs a) {
 #define CDDPM_X6_FOLD 3
 #endif
     constexpr int FOLD = (TAPS == 9) ? CDDPM_X6_FOLD : (TAPS == 4 ? 2 : 1);   // taps per accumulation group
-    constexpr int WSLOTS = 128 * 12;                    // 16-B slots of a weight slab
-    constexpr int WK = WSLOTS / THREADS;                // per thread: 3
+    constexpr int WSLOTS = 128 * SP;                    // 16-B slots of a weight slab
+    constexpr int WK = WSLOTS / THREADS;                // per thread: 3 | 2
     static_assert(WSLOTS % THREADS == 0, "weight slab must divide evenly");
 
     extern __shared__ v4f lds[];
-    v4f* ldsA = lds;                    // NPIX * 12 slots
-    v4f* ldsW = lds + NPIX * 12;        // 2 * WSLOTS
+    v4f* ldsA = lds;                    // NPIX * SP slots
+    v4f* ldsW = lds + NPIX * SP;        // 2 * WSLOTS
     v4f* ldsC = ldsW + 2 * WSLOTS;      // GroupNorm/FiLM coefficients of this sample (3 x Cin floats)
 
     const int tid = threadIdx.x;
@@ -116,6 +140,11 @@ __global__ __launch_bounds__(64 * ROWS) void conv_x6_kernel(const ConvArgs a) {
     const int b = UP2 ? (bid >> 2) : bid;
     const int pa = cls >> 1, pb = cls & 1;
     const int y0 = ty * ROWS, x0 = tx * 32;
+
+    // 16-B slot of (row = pixel or cout row, split s, u = channel / 8)
+    auto slot_of = [](int row, int sp, int u) -> int {
+        return (NS == 3) ? (row * 12 + 4 * sp + (u ^ ((row >> 2) & 3))) : (row * 8 + ((4 * sp + u) ^ ((row >> 1) & 7)));
+    };
 
     const int Cin = a.C0 + a.C1;
     const int nch_main = Cin >> 5;
@@ -192,13 +221,11 @@ __global__ __launch_bounds__(64 * ROWS) void conv_x6_kernel(const ConvArgs a) {
             }
             const int q = (tid >> 3) + (THREADS / 8) * k;
             if (q < NPIX) {
-                bf16x4 h, m, l;
-                split3x4(v, h, m, l);
+                typename SplitT<NS>::v4 t[NS];
+                split_x4<NS>(v, t);
                 // 4 channels = half a slot: slot u = c4 >> 1 of each split, half c4 & 1
-                const int o = (q * 12 + ((c4 >> 1) ^ ((q >> 2) & 3))) * 2 + (c4 & 1);
-                dst[o] = __builtin_bit_cast(v2f, h);
-                dst[o + 8] = __builtin_bit_cast(v2f, m);
-                dst[o + 16] = __builtin_bit_cast(v2f, l);
+#pragma unroll
+                for (int sp = 0; sp < NS; ++sp) dst[slot_of(q, sp, c4 >> 1) * 2 + (c4 & 1)] = __builtin_bit_cast(v2f, t[sp]);
             }
         }
     };
@@ -212,63 +239,50 @@ __global__ __launch_bounds__(64 * ROWS) void conv_x6_kernel(const ConvArgs a) {
             for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; tot[i][j][r] = 0.f; }
 
     // B operand (weights) LDS offsets: row j = cout within the 128 block
-    int boff[2], bsw[2];
+    int brow[2];
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-        const int j = 64 * wn + 32 * nt + li;
-        boff[nt] = j * 12;
-        bsw[nt] = (j >> 2) & 3;
-    }
-
-#define X6_MFMA4(A, B)                                                                                     \
-    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0], B[0], acc[0][0], 0, 0, 0);                   \
-    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0], B[1], acc[0][1], 0, 0, 0);                   \
-    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[1], B[0], acc[1][0], 0, 0, 0);                   \
-    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[1], B[1], acc[1][1], 0, 0, 0);
-
-#define X6_MFMA4Z(A, B)                                                                                    \
-    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0], B[0], zero16, 0, 0, 0);                      \
-    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0], B[1], zero16, 0, 0, 0);                      \
-    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[1], B[0], zero16, 0, 0, 0);                      \
-    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[1], B[1], zero16, 0, 0, 0);
+    for (int nt = 0; nt < 2; ++nt) brow[nt] = 64 * wn + 32 * nt + li;
 
     // `first`: the accumulators restart here (C = 0 in the first MFMA of each tile, no register clearing)
     auto compute = [&](int tap, int buf, bool first) {
         const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         const int ky = (TAPS == 9) ? (tap / 3) : (UP2 ? (tap >> 1) : 0);
         const int kx = (TAPS == 9) ? (tap - 3 * ky) : (UP2 ? (tap & 1) : 0);
-        int aoff[2], asw[2];
+        int arow[2];
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            const int q = (2 * wm + mt + ky) * PW + li + kx;
-            aoff[mt] = q * 12;
-            asw[mt] = (q >> 2) & 3;
-        }
+        for (int mt = 0; mt < 2; ++mt) arow[mt] = (2 * wm + mt + ky) * PW + li + kx;
         const v4f* wb = ldsW + buf * WSLOTS;
-        auto A = [&](int mt, int s, int u) -> bf16x8 { return __builtin_bit_cast(bf16x8, ldsA[aoff[mt] + 4 * s + (u ^ asw[mt])]); };
-        auto Bf = [&](int nt, int s, int u) -> bf16x8 { return __builtin_bit_cast(bf16x8, wb[boff[nt] + 4 * s + (u ^ bsw[nt])]); };
+        // products kept, smallest first: NS = 3: lh hl mm mh hm hh;  NS = 2: mh hm hh
+        constexpr int NP = (NS == 3) ? 6 : 3;
+        constexpr int PA[6] = {NS == 3 ? 2 : 1, 0, 1, 1, 0, 0};      // split index of the A term
+        constexpr int PB[6] = {0, NS == 3 ? 2 : 1, NS == 3 ? 1 : 0, 0, 1, 0};
 #pragma unroll
         for (int jk = 0; jk < 2; ++jk) {
             const int u = 2 * jk + lh;
-            bf16x8 ah[2], am[2], al[2], bh[2], bm[2], bl[2];
-            ah[0] = A(0, 0, u); ah[1] = A(1, 0, u);
-            bh[0] = Bf(0, 0, u); bh[1] = Bf(1, 0, u);
-            bm[0] = Bf(0, 1, u); bm[1] = Bf(1, 1, u);
-            am[0] = A(0, 1, u); am[1] = A(1, 1, u);
-            bl[0] = Bf(0, 2, u); bl[1] = Bf(1, 2, u);
-            al[0] = A(0, 2, u); al[1] = A(1, 2, u);
-            // smallest terms first
-#ifdef CDDPM_X9      // diagnostic build: all nine partial products (the three dropped ones are below 2^-24 |a b|)
-            X6_MFMA4(al, bl)
-            X6_MFMA4(am, bl)
-            X6_MFMA4(al, bm)
-#endif
-            if (jk == 0 && first) { X6_MFMA4Z(al, bh) } else { X6_MFMA4(al, bh) }
-            X6_MFMA4(ah, bl)
-            X6_MFMA4(am, bm)
-            X6_MFMA4(am, bh)
-            X6_MFMA4(ah, bm)
-            X6_MFMA4(ah, bh)
+            frag fa[NS][2], fb[NS][2];
+#pragma unroll
+            for (int sp = 0; sp < NS; ++sp)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    fa[sp][i] = __builtin_bit_cast(frag, ldsA[slot_of(arow[i], sp, u)]);
+                    fb[sp][i] = __builtin_bit_cast(frag, wb[slot_of(brow[i], sp, u)]);
+                }
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                const int sa = (NS == 3) ? PA[p] : (p == 0 ? 1 : 0);
+                const int sb = (NS == 3) ? PB[p] : (p == 1 ? 1 : 0);
+                if (jk == 0 && p == 0 && first) {       // uniform branch: restart the chains on an inline C = 0
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) acc[i][j] = SplitT<NS>::mfma(fa[sa][i], fb[sb][j], zero16);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) acc[i][j] = SplitT<NS>::mfma(fa[sa][i], fb[sb][j], acc[i][j]);
+                }
+            }
         }
     };
 
@@ -322,8 +336,6 @@ __global__ __launch_bounds__(64 * ROWS) void conv_x6_kernel(const ConvArgs a) {
             }
         }
     }
-#undef X6_MFMA4
-#undef X6_MFMA4Z
 
     __syncthreads();   // every wave is done with the patch / weight buffers before they become transpose space
     // ---- epilogue: as conv_mfma.hip -- each wave transposes its 64 x 64 tile through a private 8-KB LDS region so
@@ -344,6 +356,7 @@ __global__ __launch_bounds__(64 * ROWS) void conv_x6_kernel(const ConvArgs a) {
                     tr[(mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * 32 + li] = tot[mt][nt][r];
             __builtin_amdgcn_wave_barrier();
             const v4f bias = a.bias ? *reinterpret_cast<const v4f*>(a.bias + co) : v4f{0.f, 0.f, 0.f, 0.f};
+            const float wsc = (NS == 2) ? a.wscale_inv : 1.0f;      // fp16 weights were pre-scaled by a power of two
             v4f ssum = v4f{0.f, 0.f, 0.f, 0.f}, ssq = ssum;
 #pragma unroll
             for (int hb = 0; hb < 2; ++hb) {
@@ -368,7 +381,7 @@ __global__ __launch_bounds__(64 * ROWS) void conv_x6_kernel(const ConvArgs a) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
                     if (ok[i]) {
-                        const v4f o = val[i] + bias + rsd[i];
+                        const v4f o = val[i] * wsc + bias + rsd[i];
                         *reinterpret_cast<v4f*>(a.out + oidx[i]) = o;
                         ssum += o;
                         ssq += o * o;
@@ -405,12 +418,18 @@ __global__ __launch_bounds__(64 * ROWS) void conv_x6_kernel(const ConvArgs a) {
 #endif
 }
 
-bool conv_x6_enabled() {
-    static const bool on = [] { const char* e = getenv("CDDPM_CONV"); return !(e && strcmp(e, "f32") == 0); }();
-    return on;
+int conv_mode() {
+    static const int mode = [] {
+        const char* e = getenv("CDDPM_CONV");
+        if (e && strcmp(e, "f32") == 0) return 0;
+        if (e && strcmp(e, "x6") == 0) return 1;
+        return 2;                                   // "h3" / unset: fp16 two-term split, three products
+    }();
+    return mode;
 }
 
-void launch_conv_x6(const ConvArgs& a, hipStream_t stream) {
+template <int NS>
+static void launch_split(const ConvArgs& a, hipStream_t stream) {
     constexpr int ROWS = 8;
     const bool up2 = (a.taps == 4);
     const int gh = up2 ? a.H / 2 : a.H, gw = up2 ? a.W / 2 : a.W;
@@ -418,23 +437,28 @@ void launch_conv_x6(const ConvArgs& a, hipStream_t stream) {
     const unsigned grid = (unsigned)(a.B * (up2 ? 4 : 1) * tilesX * tilesY * (a.Cout / 128));
     const size_t coef_lds = a.coef ? (size_t)3 * (a.C0 + a.C1) * sizeof(float) : 0;
     auto need = [&](int npix) {
-        const size_t main = (size_t)(npix * 12 + 2 * 128 * 12) * 16 + coef_lds;
+        const size_t main = (size_t)(npix + 2 * 128) * (4 * NS) * 16 + coef_lds;
         const size_t tr = (size_t)ROWS * 2048 * sizeof(float);      // epilogue transpose regions alias the buffers
         return main > tr ? main : tr;
     };
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_x6_kernel<9, ROWS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_x6_kernel<1, ROWS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_x6_kernel<4, ROWS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_split_kernel<9, ROWS, NS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_split_kernel<1, ROWS, NS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_split_kernel<4, ROWS, NS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr = true;
     }
-    if (a.taps == 9) hipLaunchKernelGGL((conv_x6_kernel<9, ROWS>), dim3(grid), dim3(64 * ROWS), need((ROWS + 2) * 34), stream, a);
-    else if (a.taps == 1) hipLaunchKernelGGL((conv_x6_kernel<1, ROWS>), dim3(grid), dim3(64 * ROWS), need(ROWS * 32), stream, a);
-    else hipLaunchKernelGGL((conv_x6_kernel<4, ROWS>), dim3(grid), dim3(64 * ROWS), need((ROWS + 1) * 33), stream, a);
+    if (a.taps == 9) hipLaunchKernelGGL((conv_split_kernel<9, ROWS, NS>), dim3(grid), dim3(64 * ROWS), need((ROWS + 2) * 34), stream, a);
+    else if (a.taps == 1) hipLaunchKernelGGL((conv_split_kernel<1, ROWS, NS>), dim3(grid), dim3(64 * ROWS), need(ROWS * 32), stream, a);
+    else hipLaunchKernelGGL((conv_split_kernel<4, ROWS, NS>), dim3(grid), dim3(64 * ROWS), need((ROWS + 1) * 33), stream, a);
 }
 
-// ---- host side: bf16 round-to-nearest-even and the three-way split
+void launch_conv_split(const ConvArgs& a, hipStream_t stream) {
+    if (conv_mode() == 1) launch_split<3>(a, stream);
+    else launch_split<2>(a, stream);
+}
+
+// ---- host side: 16-bit round-to-nearest-even conversions and the splits
 static inline uint16_t bf16_rne(float x) {
     uint32_t u;
     memcpy(&u, &x, 4);
@@ -448,30 +472,49 @@ static inline float bf16_to_f(uint16_t h) {
     memcpy(&f, &u, 4);
     return f;
 }
+static inline uint16_t f16_rne(float x) { const _Float16 h = (_Float16)x; uint16_t b; memcpy(&b, &h, 2); return b; }   // compiler RNE, subnormals kept
+static inline float f16_to_f(uint16_t b) { _Float16 h; memcpy(&h, &b, 2); return (float)h; }
 
-// w: PyTorch [Cout][Cin][k][k] (taps = k*k) -> [Cout/128][Cin/32][taps][128 rows][12 slots][8 bf16]:
-// slot (split s, u = channel/8 within the chunk) of row j stored at 4 s + (u ^ ((j>>2)&3)); 6 bytes per weight.
-void pack_conv_weights_x6(const float* w, int Cout, int Cin, int taps, void* dst_) {
+// power-of-two pre-scale of a weight tensor for the fp16 split: the largest e in [0, 24] with max|w| * 2^e < 2^14
+int conv_weight_exp(const float* w, size_t n) {
+    if (conv_mode() != 2) return 0;
+    float mx = 0.f;
+    for (size_t i = 0; i < n; ++i) { const float v = w[i] < 0 ? -w[i] : w[i]; if (v > mx) mx = v; }
+    int e = 24;
+    while (e > 0 && ldexpf(mx, e) >= 16384.0f) --e;
+    return e;
+}
+
+// w: PyTorch [Cout][Cin][k][k] (taps = k*k) -> [Cout/128][Cin/32][taps][128 rows][4 NS slots][8 x 16 bit]
+//   NS = 3 (bf16): slot (split s, u = channel/8 in the chunk) of row j at 4 s + (u ^ ((j>>2)&3)); 6 bytes per weight
+//   NS = 2 (fp16): w * 2^wexp is split; slot at (4 s + u) ^ ((j>>1)&7); 4 bytes per weight
+void pack_conv_weights_split(const float* w, int Cout, int Cin, int taps, void* dst_, int wexp) {
     uint16_t* dst = static_cast<uint16_t*>(dst_);
     const int ncb = Cout / 128, nch = Cin / 32;
+    const int ns = (conv_mode() == 1) ? 3 : 2, sp = 4 * ns;
     for (int cb = 0; cb < ncb; ++cb)
         for (int ch = 0; ch < nch; ++ch)
             for (int t = 0; t < taps; ++t) {
-                uint16_t* img = dst + (((size_t)cb * nch + ch) * taps + t) * (128 * 12 * 8);
+                uint16_t* img = dst + (((size_t)cb * nch + ch) * taps + t) * (128 * sp * 8);
                 for (int j = 0; j < 128; ++j)
                     for (int u = 0; u < 4; ++u)
                         for (int e = 0; e < 8; ++e) {
                             const int co = cb * 128 + j, ci = ch * 32 + 8 * u + e;
-                            const float x = w[((size_t)co * Cin + ci) * taps + t];
-                            const uint16_t h = bf16_rne(x);
-                            const float r1 = x - bf16_to_f(h);
-                            const uint16_t m = bf16_rne(r1);
-                            const float r2 = r1 - bf16_to_f(m);
-                            const uint16_t l = bf16_rne(r2);
-                            const int us = u ^ ((j >> 2) & 3);
-                            img[(size_t)(j * 12 + 0 + us) * 8 + e] = h;
-                            img[(size_t)(j * 12 + 4 + us) * 8 + e] = m;
-                            img[(size_t)(j * 12 + 8 + us) * 8 + e] = l;
+                            float r = w[((size_t)co * Cin + ci) * taps + t];
+                            if (ns == 3) {
+                                for (int s3 = 0; s3 < 3; ++s3) {
+                                    const uint16_t q = bf16_rne(r);
+                                    r -= bf16_to_f(q);
+                                    img[(size_t)(j * 12 + 4 * s3 + (u ^ ((j >> 2) & 3))) * 8 + e] = q;
+                                }
+                            } else {
+                                r = ldexpf(r, wexp);
+                                for (int s2 = 0; s2 < 2; ++s2) {
+                                    const uint16_t q = f16_rne(r);
+                                    r -= f16_to_f(q);
+                                    img[(size_t)(j * 8 + ((4 * s2 + u) ^ ((j >> 1) & 7))) * 8 + e] = q;
+                                }
+                            }
                         }
             }
 }

@@ -34,26 +34,33 @@ struct ConvArgs {
     // optional GroupNorm statistics of the OUTPUT tensor, produced by the epilogue: fp32 records
     // [B][nrec = 2 * tilesX * tilesY][Cout][2] = per-channel (sum, sum of squares) over the 64 pixels a wave owns
     float* stats;
+    float wscale_inv;    // conv_mode() == 2: 2^-wexp of the packed weights (main and skip segment share it); else unused
 };
 inline int conv_stat_records(int H, int W) { return 2 * ((W + 31) / 32) * ((H + 3) / 4); }
 inline int conv_stat_records_up2(int H, int W) { return 8 * ((W / 2 + 31) / 32) * ((H / 2 + 3) / 4); }
 void launch_conv(const ConvArgs& a, hipStream_t stream);
 // wave-specialised persistent variant (conv_ws.hip); launch_conv forwards to it when CDDPM_CONV_WS=1 is set
 void launch_conv_ws(const ConvArgs& a, hipStream_t stream);
-// fp32-accurate variant on the bf16 matrix pipe (conv_x6.hip: operands split exactly into three bf16 terms, six
-// bf16 MFMAs per product group). The default; CDDPM_CONV=f32 selects the fp32-MFMA kernels of conv_mfma.hip. The
-// choice is made once per process and also selects the packed weight format (pack_conv_weights / packed_conv_floats).
-bool conv_x6_enabled();
-void launch_conv_x6(const ConvArgs& a, hipStream_t stream);
-void pack_conv_weights_x6(const float* w /*[Cout][Cin][k][k]*/, int Cout, int Cin, int taps, void* dst);
+// fp32-accurate variants on the 16-bit matrix pipe (conv_x6.hip): operands split into 16-bit terms whose partial
+// products are exact in fp32. conv_mode(): 2 = fp16 two-term split, three MFMAs per product group (default,
+// CDDPM_CONV=h3 or unset); 1 = bf16 three-term split, six MFMAs (CDDPM_CONV=x6); 0 = the fp32-MFMA kernels of
+// conv_mfma.hip (CDDPM_CONV=f32). Chosen once per process; it also selects the packed weight format.
+int conv_mode();
+void launch_conv_split(const ConvArgs& a, hipStream_t stream);
+// mode 2 only (else 0): power-of-two pre-scale exponent of a weight tensor, max|w| * 2^e in [2^13, 2^14)
+int conv_weight_exp(const float* w, size_t n);
+void pack_conv_weights_split(const float* w /*[Cout][Cin][k][k]*/, int Cout, int Cin, int taps, void* dst, int wexp);
 
 // packed weight image sizes / packing (host side, cddpm_api.hip)
 // fp32 layout: [Cout/128][Cin/32][taps][128 rows x 8 slots of float4], slot s of row j stored at s ^ ((j>>1)&7)
 // x6 layout  : [Cout/128][Cin/32][taps][128 rows x 12 slots of 8 bf16] (conv_x6.hip), 1.5 floats per weight
+// split layouts (conv_x6.hip): [..][128 rows x 4 NS slots of 8 x 16 bit]: 1.5 (bf16 x 3) | 1 (fp16 x 2) floats per weight
 size_t packed_conv_floats(int Cout, int Cin, int taps);
-void pack_conv_weights(const float* w /*[Cout][Cin][k][k]*/, int Cout, int Cin, int taps, float* dst);
+// wexp: conv_weight_exp() of the tensor (and of every tensor accumulated into the same output tile); ignored unless mode 2
+void pack_conv_weights(const float* w /*[Cout][Cin][k][k]*/, int Cout, int Cin, int taps, float* dst, int wexp);
 // folded weights of nearest-x2-upsample + 3x3: 4 parity classes x 4 taps = 4 * packed_conv_floats(Cout, Cin, 4) floats
-void pack_conv_weights_up2(const float* w /*[Cout][Cin][3][3]*/, int Cout, int Cin, float* dst);
+// returns the pre-scale exponent it chose for the folded weights (0 unless mode 2)
+int pack_conv_weights_up2(const float* w /*[Cout][Cin][3][3]*/, int Cout, int Cin, float* dst);
 
 // ------------------------------------------------------------------------------------------------
 // GroupNorm(32) statistics and per-(sample, channel) coefficients (norm_kernels.hip)

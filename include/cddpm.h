@@ -175,15 +175,18 @@ int cddpm_op_gn_coef(cddpm_handle h, const float* src0_dev, int C0, const float*
                      float* coef_dev, int B, int HW, void* stream);
 
 /* host-only: the packed weight image of one convolution as the active kernel family expects it (no GPU needed).
- * format = 1: conv_x6.hip (default) -- every weight split exactly into three bf16 terms (hi + mid + lo == w in fp32),
- *   [Cout/128][Cin/32][taps][128 rows][12 slots of 8 bf16], slot (split s, u = channel/8 in the 32-channel chunk) of
- *   row j at 4 s + (u ^ ((j >> 2) & 3)); 6 bytes per weight.
+ * format = 2: conv_x6.hip, fp16 split (default) -- w * 2^e (e = *scale_exp_out, the largest exponent <= 24 that keeps
+ *   max|w| * 2^e below 2^14) split into two fp16 terms, hi + mid == w * 2^e to within 2^-23 relative (rms 0.73 x 2^-24);
+ *   [Cout/128][Cin/32][taps][128 rows][8 slots of 8 fp16], slot (split s, u = channel/8 in the 32-channel chunk) of
+ *   row j at (4 s + u) ^ ((j >> 1) & 7); 4 bytes per weight.
+ * format = 1: conv_x6.hip, bf16 split (CDDPM_CONV=x6) -- three bf16 terms, hi + mid + lo == w exactly in fp32;
+ *   [..][128 rows][12 slots of 8 bf16], slot (s, u) of row j at 4 s + (u ^ ((j >> 2) & 3)); 6 bytes per weight.
  * format = 0: conv_mfma.hip (CDDPM_CONV=f32) -- fp32, [..][128 rows][8 slots of 4 floats], slot s of row j at
  *   s ^ ((j >> 1) & 7); 4 bytes per weight.
  * cddpm_packed_conv_bytes returns the image size; cddpm_pack_conv_weights fills dst_host (that many bytes) from
  * PyTorch-layout w_host [Cout][Cin][k][k] (taps = k*k in {1, 9}) and returns the format, or -1 on a bad shape. */
 size_t cddpm_packed_conv_bytes(int Cout, int Cin, int taps);
-int cddpm_pack_conv_weights(const float* w_host, int Cout, int Cin, int taps, void* dst_host);
+int cddpm_pack_conv_weights(const float* w_host, int Cout, int Cin, int taps, void* dst_host, int* scale_exp_out);
 
 /* standalone attention core on qkv NHWC [B,N,3C] (q | k | v, heads = contiguous groups of head_channels):
  * out [B,N,C] = softmax(q k^T / sqrt(head_channels)) v  (QKVAttention, OpenAI_Unet.py:457-476). */

@@ -147,23 +147,25 @@ def _bf16_rne(x: np.ndarray) -> np.ndarray:
     return (u.astype(np.uint32) << 16).view(np.float32)
 
 
-def test_bf16_split_weight_image_is_exact():
-    """The convolution forms fp32 products from three bf16 terms per operand (conv_x6.hip); the whole parity claim
-    rests on hi + mid + lo == w EXACTLY. Checked on the host packer through the C ABI (no GPU), together with the
-    documented image layout (include/cddpm.h)."""
+def test_split_weight_image_reproduces_the_weights():
+    """The convolution forms fp32 products from a few 16-bit terms per operand (conv_x6.hip); the whole parity claim
+    rests on the terms adding up to the operand: exactly for the bf16 three-term split, to within 2^-23 relative (one
+    fp32 ulp, most values exactly) for the pre-scaled fp16 two-term split. Checked on the host packer through the C ABI (no GPU),
+    together with the documented image layouts (include/cddpm.h)."""
     lib = load_pkg("_lib").load_library()
     Cout, Cin, taps = 128, 64, 9
     rng = np.random.default_rng(0)
     w = (rng.standard_normal((Cout, Cin, 3, 3)) * 0.05).astype(np.float32)
-    w.flat[:10] = [0.0, -0.0, 1.0, -1.0, 3.0e-20, 65280.0, 1.0 + 2.0 ** -23, -(2.0 ** -100), 0.1, 1.0 - 2.0 ** -24]
+    w.flat[:10] = [0.0, -0.0, 0.25, -0.25, 3.0e-20, 0.2, 0.1 + 2.0 ** -23, -(2.0 ** -100), 0.1, 0.25 - 2.0 ** -26]
     n = lib.cddpm_packed_conv_bytes(Cout, Cin, taps)
     assert lib.cddpm_packed_conv_bytes(100, Cin, taps) == 0 and lib.cddpm_packed_conv_bytes(Cout, Cin, 4) == 0
     buf = (ctypes.c_uint8 * n)()
-    fmt = lib.cddpm_pack_conv_weights(w.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), Cout, Cin, taps, buf)
-    assert fmt in (0, 1)
+    wexp = ctypes.c_int(-1)
+    fmt = lib.cddpm_pack_conv_weights(w.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), Cout, Cin, taps, buf, ctypes.byref(wexp))
+    assert fmt in (0, 1, 2)
     wt = w.reshape(Cout, Cin, taps)
     if fmt == 0:                                    # fp32-MFMA image (CDDPM_CONV=f32)
-        assert n == w.size * 4
+        assert n == w.size * 4 and wexp.value == 0
         img = np.frombuffer(buf, np.float32).reshape(Cin // 32, taps, 128, 8, 4)
         for j in (0, 1, 2, 77, 127):
             for sl in range(8):
@@ -171,20 +173,34 @@ def test_bf16_split_weight_image_is_exact():
                 want = wt[j].reshape(Cin // 32, 8, 4, taps)[:, sl].transpose(0, 2, 1)
                 assert np.array_equal(got, want)
         return
-    assert n == w.size * 6
-    img = np.frombuffer(buf, np.uint16).reshape(Cin // 32, taps, 128, 12, 8)
-    parts = np.zeros((3, Cout, Cin, taps), np.float32)
+    ns = 3 if fmt == 1 else 2
+    assert n == w.size * 2 * ns
+    img = np.frombuffer(buf, np.uint16).reshape(Cin // 32, taps, 128, 4 * ns, 8)
+    parts = np.zeros((ns, Cout, Cin, taps), np.float32)
     for j in range(128):
-        key = (j >> 2) & 3
-        for s in range(3):
+        for s in range(ns):
             for u in range(4):
-                v = (img[:, :, j, 4 * s + (u ^ key), :].astype(np.uint32) << 16).view(np.float32)   # [chunk][tap][8]
+                slot = (4 * s + (u ^ ((j >> 2) & 3))) if ns == 3 else ((4 * s + u) ^ ((j >> 1) & 7))
+                raw = img[:, :, j, slot, :]                                                     # [chunk][tap][8]
+                v = (raw.astype(np.uint32) << 16).view(np.float32) if ns == 3 else raw.view(np.float16).astype(np.float32)
                 parts[s, j].reshape(Cin // 32, 4, 8, taps)[:, u] = v.transpose(0, 2, 1)
-    hi, mid, lo = parts.astype(np.float64)
-    assert np.array_equal(hi + mid + lo, wt.astype(np.float64)), "three-term bf16 split must reproduce every weight exactly"
-    assert np.array_equal(parts[0], _bf16_rne(wt))                              # hi = bf16(w), round to nearest even
-    assert np.array_equal(parts[1], _bf16_rne(wt - parts[0]))                   # mid = bf16(w - hi)
-    assert (np.abs(mid) <= np.abs(hi) * 2.0 ** -8 + 1e-45).all() and (np.abs(lo) <= np.abs(hi) * 2.0 ** -16 + 1e-45).all()
+    total = parts.astype(np.float64).sum(axis=0)
+    if ns == 3:
+        assert wexp.value == 0
+        assert np.array_equal(total, wt.astype(np.float64)), "three-term bf16 split must reproduce every weight exactly"
+        assert np.array_equal(parts[0], _bf16_rne(wt))                              # hi = bf16(w), round to nearest even
+        assert np.array_equal(parts[1], _bf16_rne(wt - parts[0]))                   # mid = bf16(w - hi)
+    else:
+        e = wexp.value
+        mx = float(np.abs(w).max())
+        assert 0 <= e <= 24 and 8192.0 <= mx * 2.0 ** e < 16384.0                   # max |w| 2^e in [2^13, 2^14)
+        ws = wt.astype(np.float64) * 2.0 ** e
+        err = np.abs(total - ws)
+        # two 11-bit terms: one fp32 ulp at worst while mid is a normal fp16 (|w 2^e| >= 2^-2), an absolute 2^-25 below
+        assert (err <= np.maximum(np.abs(ws) * 2.0 ** -23, 2.0 ** -25)).all()
+        big = np.abs(ws) >= 0.25
+        assert np.sqrt(np.mean((err[big] / np.abs(ws[big])) ** 2)) < 2.0 ** -24 and (err[big] == 0).mean() > 0.5
+        assert np.array_equal(parts[0], (wt * np.float32(2.0 ** e)).astype(np.float16).astype(np.float32))   # hi = fp16(w 2^e)
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")

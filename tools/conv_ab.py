@@ -73,7 +73,7 @@ def main():
                 env = dict(os.environ, CDDPM_LIB=os.path.join(CSRC, f"libcddpm_hip_{lib}.so"))
                 if opt == "ws":
                     env["CDDPM_CONV_WS"] = "1"
-                if opt in ("f32", "x6"):
+                if opt in ("f32", "x6", "h3"):
                     env["CDDPM_CONV"] = opt
                 if opt == "zero":
                     env["CDDPM_BENCH_ZERO"] = "1"

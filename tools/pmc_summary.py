@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Summarise the rocprofv3 --pmc passes of tools/pmc_passes.sh for the dominant kernel (default conv_x6_kernel<9,...>;
+"""Summarise the rocprofv3 --pmc passes of tools/pmc_passes.sh for the dominant kernel (default conv_split_kernel<9,...>;
 third argument = another kernel-name substring, e.g. "conv_mfma_kernel<9" for CDDPM_CONV=f32 runs).
 
 Applies the gfx950 corrections of MI355X_MICROARCH.md: FETCH_SIZE (KB) under-reports wide (16 B/lane) coalesced
@@ -13,7 +13,7 @@ import os
 import sys
 
 root, out = sys.argv[1], sys.argv[2]
-KEY = sys.argv[3] if len(sys.argv) > 3 else "conv_x6_kernel<9"
+KEY = sys.argv[3] if len(sys.argv) > 3 else "conv_split_kernel<9"
 
 
 def load(tag):

@@ -7,6 +7,9 @@
 //   f32      fp32 MFMA, one accumulation chain            f32x2lvl  fp32 MFMA, folded every 288 (one 32-channel chunk)
 //   x3       hi*hi + hi*mid + mid*hi                       x6        + mid*mid + hi*lo + lo*hi
 //   x8       + mid*lo + lo*mid                              x9        + lo*lo        (x6/x9 also folded every 288)
+//   h3       fp16 instead of bf16: x = hi + mid with 11-bit terms (|x - hi - mid| <= 2^-24 |x| while mid stays a normal
+//            fp16, i.e. |x| >= 0.25 -- smaller values keep an ABSOLUTE error <= 2^-25; B is pre-scaled by 2^12 and the
+//            result unscaled, A is not), three products hi*hi + hi*mid + mid*hi on v_mfma_f32_32x32x16_f16
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdio>
@@ -15,6 +18,7 @@
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ void split3(float x, __bf16& h, __bf16& m, __bf16& l) {
     h = (__bf16)x;
@@ -22,6 +26,28 @@ __device__ __forceinline__ void split3(float x, __bf16& h, __bf16& m, __bf16& l)
     m = (__bf16)r1;
     const float r2 = r1 - (float)m;
     l = (__bf16)r2;
+}
+
+// fp16 two-term split, three products; B scaled by 2^12 (exact), result unscaled at the end
+__global__ void gemm_h3(const float* A, const float* B, float* C, int K, int fold) {
+    const int lane = threadIdx.x, r = lane & 31, h = lane >> 5;
+    f32x16 acc, tot;
+    for (int i = 0; i < 16; ++i) { acc[i] = 0.f; tot[i] = 0.f; }
+    for (int k = 0; k < K; k += 16) {
+        f16x8 ah, am, bh, bm;
+        for (int j = 0; j < 8; ++j) {
+            const float x = A[r * K + k + 8 * h + j];
+            ah[j] = (_Float16)x; am[j] = (_Float16)(x - (float)ah[j]);
+            const float y = B[(k + 8 * h + j) * 32 + r] * 4096.0f;
+            bh[j] = (_Float16)y; bm[j] = (_Float16)(y - (float)bh[j]);
+        }
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bm, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(am, bh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
+        if (fold && ((k + 16) % fold) == 0) { tot += acc; for (int i = 0; i < 16; ++i) acc[i] = 0.f; }
+    }
+    tot += acc;
+    for (int i = 0; i < 16; ++i) C[((i & 3) + 8 * (i >> 2) + 4 * h) * 32 + r] = tot[i] * (1.0f / 4096.0f);
 }
 
 // A: [32][K] row-major, B: [K][32] row-major, C: [32][32]
@@ -98,6 +124,12 @@ int main() {
         RUN(8, 0, "x8")
         RUN(9, 0, "x9")
         RUN(9, 288, "x9x2lvl")
+        RUN(6, 96, "x6 fold96")
+#define RUNH(FOLD, NAME) hipLaunchKernelGGL(gemm_h3, dim3(1), dim3(64), 0, 0, dA, dB, dC, K, FOLD); \
+        hipMemcpy(C.data(), dC, 4096, hipMemcpyDeviceToHost); report(NAME, C.data());
+        RUNH(0, "h3")
+        RUNH(288, "h3x2lvl")
+        RUNH(96, "h3 fold96")
         hipFree(dA); hipFree(dB); hipFree(dC);
     }
     return 0;
