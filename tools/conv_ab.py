@@ -22,6 +22,8 @@ SHAPES = [
     ("conv1 128>128 @128", 128, 0, 128, 3, 128, 128, 1, 1, 0, 0, 0),
     ("conv2 128>128 @128 +res", 128, 0, 128, 3, 128, 128, 1, 1, 0, 1, 0),
     ("plain 128>128 @128 nocoef", 128, 0, 128, 3, 128, 128, 0, 0, 0, 0, 0),
+    ("coef only 128>128 @128", 128, 0, 128, 3, 128, 128, 1, 0, 0, 0, 0),
+    ("silu only 128>128 @128", 128, 0, 128, 3, 128, 128, 0, 1, 0, 0, 0),
     ("up conv1 256>256 @128", 256, 0, 256, 3, 128, 128, 1, 1, 1, 0, 0),
     ("cat conv1 512>256 @64", 256, 256, 256, 3, 64, 64, 1, 1, 0, 0, 0),
     ("conv2 256>256 @64 +skip512", 256, 0, 256, 3, 64, 64, 1, 1, 0, 0, 512),
@@ -29,6 +31,7 @@ SHAPES = [
     ("cat conv1 384>128 @128", 256, 128, 128, 3, 128, 128, 1, 1, 0, 0, 0),
 ]
 PHASES = ["prologue", "patch stage", "weight stage", "mfma compute", "chunk fold", "epilogue"]
+PHASES8 = ["prologue", "chunk barrier", "patch store", "weight store", "stage barrier", "compute", "fold", "epilogue"]
 
 
 def child(B, iters):
@@ -48,6 +51,10 @@ def child(B, iters):
             row["clock_GHz"] = round(st[40] / st[41] * 0.1, 3)
         if os.environ.get("CDDPM_CONV_WS") == "1" and sum(st[:4]):
             row["ws_cycles"] = {"matrix work": int(st[0]), "matrix barrier": int(st[1]), "staging work": int(st[2]), "staging barrier": int(st[3])}
+        elif os.environ.get("AB_PHASES8") and sum(st[:16]):
+            for wv in (0, 1):
+                tt = [st[wv * 8 + i] for i in range(8)]
+                row["wave%d" % (wv * 4)] = {p: round(t / max(1, sum(tt)), 3) for p, t in zip(PHASES8, tt)}
         elif sum(tot):
             row["phase_share"] = {p: round(t / sum(tot), 4) for p, t in zip(PHASES, tot)}
         out.append(row)
@@ -94,6 +101,9 @@ def main():
                     line += "  " + json.dumps(runs[0][i]["phase_share"])
                 if "clock_GHz" in runs[0][i]:
                     line += f"  clock {runs[0][i]['clock_GHz']} GHz"
+                for wk in ("wave0", "wave4"):
+                    if wk in runs[0][i]:
+                        line += "\n        " + wk + " " + json.dumps(runs[0][i][wk])
                 if "ws_cycles" in runs[0][i]:
                     line += "  " + json.dumps(runs[0][i]["ws_cycles"])
                 print(line)

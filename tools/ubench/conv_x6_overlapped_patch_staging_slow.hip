@@ -1,3 +1,6 @@
+// ARCHIVED EXPERIMENT (not built): conv_x6.hip with two patch buffers and the next chunk's patch staged one entry per tap behind
+// the MFMAs (tap loop unrolled). Parity-green, 1.85x SLOWER than the barrier-separated staging (spills + serialised waits in the
+// unrolled stages); see DESIGN.md section 4.
 // Fused implicit-GEMM convolution for gfx950 (MI355X): fp32 accuracy on the 16-bit matrix pipe.
 //
 // Same operator as conv_mfma.hip (see there for what is fused and the reference lines it replaces:
@@ -34,6 +37,7 @@
 #include "kernels.h"
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 #include <vector>
 
 namespace cddpm {
@@ -107,10 +111,13 @@ __global__ __launch_bounds__(64 * ROWS) void conv_split_kernel(const ConvArgs a)
     constexpr int WK = WSLOTS / THREADS;                // per thread: 3 | 2
     static_assert(WSLOTS % THREADS == 0, "weight slab must divide evenly");
 
+    // OVL: the fp16 3x3 kernel keeps TWO patch buffers and stages the next chunk's patch one entry per tap behind the
+    // MFMAs of the current chunk (see the main loop); the other instantiations rewrite a single buffer between barriers.
+    constexpr bool OVL = (NS == 2 && TAPS == 9);
     extern __shared__ v4f lds[];
-    v4f* ldsA = lds;                    // NPIX * SP slots
-    v4f* ldsW = lds + NPIX * SP;        // 2 * WSLOTS
-    v4f* ldsC = ldsW + 2 * WSLOTS;      // GroupNorm/FiLM coefficients of this sample (3 x Cin floats)
+    v4f* ldsA = lds;                                  // current patch: NPIX * SP slots (OVL: one of two)
+    v4f* ldsW = lds + (OVL ? 2 : 1) * NPIX * SP;      // 2 * WSLOTS
+    v4f* ldsC = ldsW + 2 * WSLOTS;                    // GroupNorm/FiLM coefficients of this sample (3 x Cin floats)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -230,6 +237,47 @@ __global__ __launch_bounds__(64 * ROWS) void conv_split_kernel(const ConvArgs a)
         }
     };
 
+    // one patch entry at a time (OVL): source selection of a chunk, the load, and transform + split + store into `pbuf`
+    struct ChunkSrc { const float* base; int Cs, c0; bool main_seg; };
+    auto chunk_src = [&](int chunk) -> ChunkSrc {
+        ChunkSrc r;
+        r.main_seg = chunk < nch_main;
+        if (r.main_seg) {
+            const int ch = chunk << 5;
+            if (ch < a.C0) { r.base = a.src0; r.Cs = a.C0; r.c0 = ch; }
+            else           { r.base = a.src1; r.Cs = a.C1; r.c0 = ch - a.C0; }
+        } else {
+            const int ch = (chunk - nch_main) << 5;
+            if (ch < a.S0) { r.base = a.skip0; r.Cs = a.S0; r.c0 = ch; }
+            else           { r.base = a.skip1; r.Cs = a.S1; r.c0 = ch - a.S0; }
+        }
+        return r;
+    };
+    auto load_entry = [&](const ChunkSrc& cs, int k, int p_k) -> v4f {      // p_k = psrc[k] (compile-time k at the call site)
+        const int p = (cs.main_seg || ((centre >> k) & 1u)) ? p_k : -1;
+        v4f v = v4f{0.f, 0.f, 0.f, 0.f};
+        if (p >= 0) v = *reinterpret_cast<const v4f*>(cs.base + (size_t)p * cs.Cs + cs.c0 + 4 * c4);
+        return v;
+    };
+    auto store_entry = [&](int chunk, int k, int p_k, v4f v, v4f* pbuf) {
+        const bool main_seg = chunk < nch_main;
+        const int q = (tid >> 3) + (THREADS / 8) * k;
+        if (q >= NPIX) return;
+        const int p = (main_seg || ((centre >> k) & 1u)) ? p_k : -1;
+        if (p >= 0 && main_seg) {   // zero padding stays exactly zero: the conv pads AFTER the activation
+            if (have_coef) {
+                const int ci = (chunk << 3) + c4;
+                v = (v - ldsC[ci]) * ldsC[(Cin >> 2) + ci] + ldsC[2 * (Cin >> 2) + ci];
+            }
+            if (a.silu) { v.x = silu_x6(v.x); v.y = silu_x6(v.y); v.z = silu_x6(v.z); v.w = silu_x6(v.w); }
+        }
+        typename SplitT<NS>::v4 t[NS];
+        split_x4<NS>(v, t);
+        v2f* dst = reinterpret_cast<v2f*>(pbuf);
+#pragma unroll
+        for (int sp = 0; sp < NS; ++sp) dst[slot_of(q, sp, c4 >> 1) * 2 + (c4 & 1)] = __builtin_bit_cast(v2f, t[sp]);
+    };
+
     f32x16 acc[2][2], tot[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -244,13 +292,15 @@ __global__ __launch_bounds__(64 * ROWS) void conv_split_kernel(const ConvArgs a)
     for (int nt = 0; nt < 2; ++nt) brow[nt] = 64 * wn + 32 * nt + li;
 
     // `first`: the accumulators restart here (C = 0 in the first MFMA of each tile, no register clearing)
-    auto compute = [&](int tap, int buf, bool first) {
+    // lio = lane & 31, passed in so that a caller can make it opaque (keeps the unrolled OVL loop from hoisting the
+    // fragment addresses of all nine taps out of the chunk loop into ~70 VGPRs)
+    auto compute = [&](int tap, int buf, bool first, int lio) {
         const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         const int ky = (TAPS == 9) ? (tap / 3) : (UP2 ? (tap >> 1) : 0);
         const int kx = (TAPS == 9) ? (tap - 3 * ky) : (UP2 ? (tap & 1) : 0);
         int arow[2];
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) arow[mt] = (2 * wm + mt + ky) * PW + li + kx;
+        for (int mt = 0; mt < 2; ++mt) arow[mt] = (2 * wm + mt + ky) * PW + lio + kx;
         const v4f* wb = ldsW + buf * WSLOTS;
         // products kept, smallest first: NS = 3: lh hl mm mh hm hh;  NS = 2: mh hm hh
         constexpr int NP = (NS == 3) ? 6 : 3;
@@ -286,6 +336,83 @@ __global__ __launch_bounds__(64 * ROWS) void conv_split_kernel(const ConvArgs a)
         }
     };
 
+    if constexpr (OVL) {
+        // ---- main loop, overlapped patch staging. The patch of chunk c + 1 is built in the OTHER patch buffer while chunk
+        // c computes: during a 9-tap chunk every thread requests one 16-B entry per tap (taps 0..5) and, two taps later,
+        // normalises / activates / splits it and writes it (taps 2..7) -- the transform VALU work runs between the MFMA
+        // groups instead of in a burst between two workgroup barriers, and a chunk boundary costs no extra barrier. The
+        // tap loop is unrolled so that the three entries in flight live in fixed registers. After a 1-tap (skip segment)
+        // chunk the next patch is staged in one go behind its only stage.
+        v4f* const patch0 = lds;
+        v4f* const patch1 = lds + NPIX * SP;
+        {
+            const v4f* p0 = wslab(0, 0);
+#pragma unroll
+            for (int i = 0; i < WK; ++i) wreg[i] = p0[tid + THREADS * i];
+        }
+        load_act(0);
+        if (have_coef) {
+            const int nq = Cin >> 2;
+            const size_t plane = (size_t)a.B * Cin;
+            for (int i = tid; i < 3 * nq; i += THREADS) {
+                const int pl = i / nq, cq = i - pl * nq;
+                ldsC[i] = *reinterpret_cast<const v4f*>(a.coef + pl * plane + (size_t)b * Cin + 4 * cq);
+            }
+        }
+        __syncthreads();       // coefficient cache filled
+        store_act(0);          // into patch0 (ldsA == lds)
+        int buf = 0;
+        STAMP(0)
+        v4f ring[3];           // entries in flight: entry k lives in ring[k % 3]
+        for (int chunk = 0; chunk < nch; ++chunk) {
+            const bool main_seg = chunk < nch_main;
+            const bool have_next = chunk + 1 < nch;
+            v4f* const pnext = (chunk & 1) ? patch0 : patch1;
+            ldsA = (chunk & 1) ? patch1 : patch0;
+            const ChunkSrc ns = chunk_src(have_next ? chunk + 1 : chunk);
+            auto stage = [&](auto tc) {
+                constexpr int t = decltype(tc)::value;
+                const bool last_tap = main_seg ? (t == TAPS - 1) : true;
+#pragma unroll
+                for (int i = 0; i < WK; ++i) ldsW[buf * WSLOTS + tid + THREADS * i] = wreg[i];
+                const v4f* pn = last_tap ? wslab(chunk + 1, 0) : wslab(chunk, t + 1);
+#pragma unroll
+                for (int i = 0; i < WK; ++i) wreg[i] = pn[tid + THREADS * i];
+                if (main_seg && have_next) {
+                    if constexpr (t < NK) ring[t % 3] = load_entry(ns, t, psrc[t]);
+                    if constexpr (t >= 2 && t - 2 < NK) store_entry(chunk + 1, t - 2, psrc[t - 2], ring[(t - 2) % 3], pnext);
+                }
+                __syncthreads();
+                STAMP(2)
+                int lio = li;
+                asm volatile("" : "+v"(lio));
+                compute(main_seg ? t : (TAPS / 2), buf, (t % FOLD) == 0, lio);   // skip segment: centre tap
+                buf ^= 1;
+                STAMP(3)
+                if ((t % FOLD) == FOLD - 1 || last_tap) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) tot[i][j] += acc[i][j];
+                    STAMP(4)
+                }
+            };
+            static_assert(NK <= TAPS - 2, "every entry must be stored two taps after its request, inside the chunk");
+            if (main_seg) {
+                stage(std::integral_constant<int, 0>{}); stage(std::integral_constant<int, 1>{}); stage(std::integral_constant<int, 2>{});
+                stage(std::integral_constant<int, 3>{}); stage(std::integral_constant<int, 4>{}); stage(std::integral_constant<int, 5>{});
+                stage(std::integral_constant<int, 6>{}); stage(std::integral_constant<int, 7>{}); stage(std::integral_constant<int, 8>{});
+            } else {
+                stage(std::integral_constant<int, 0>{});
+                if (have_next) {        // every wave passed this chunk's barrier: the other buffer (chunk - 1's patch) is free
+                    load_act(chunk + 1);
+                    ldsA = pnext;
+                    store_act(chunk + 1);
+                    STAMP(1)
+                }
+            }
+        }
+    } else {
     // ---- main loop: weights double-buffered in LDS and prefetched through registers one stage ahead;
     //      the next chunk's patch is fetched into registers behind the last tap's MFMAs.
     {
@@ -324,7 +451,7 @@ __global__ __launch_bounds__(64 * ROWS) void conv_split_kernel(const ConvArgs a)
             // (<= 96 products per chain), `tot` sums those groups. The rounding noise of an fp32 chain grows with the
             // magnitude of its partial sums, so short chains folded into a long-lived total keep it near the
             // storage-rounding level (tools/ubench/bf16_split_accuracy.hip, tools/chain_noise.py).
-            compute(main_seg ? t : (TAPS / 2), buf, (t % FOLD) == 0);   // skip segment: centre tap
+            compute(main_seg ? t : (TAPS / 2), buf, (t % FOLD) == 0, li);   // skip segment: centre tap
             buf ^= 1;
             STAMP(3)
             if ((t % FOLD) == FOLD - 1 || last_tap) {
@@ -337,31 +464,8 @@ __global__ __launch_bounds__(64 * ROWS) void conv_split_kernel(const ConvArgs a)
         }
     }
 
-    // residual tile of this wave (16 x 16 B per lane): requested here, in one go, so that the loads fly while the waves
-    // meet at the barrier and transpose; the accumulator / fragment registers are dead by now. (Loading each batch right
-    // before its add exposed the global latency four times per wave: 12 % of the kernel on the +residual layers.)
-    v4f rsd_all[2][2][4];
-    {
-        const int cq = lane & 7, prow = lane >> 3;
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-            for (int hb = 0; hb < 2; ++hb)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int co = cb * 128 + 64 * wn + 32 * nt + 4 * cq;
-                    const int p = 8 * (4 * hb + i) + prow;
-                    const int gy = y0 + 2 * wm + (p >> 5), gx = x0 + (p & 31);
-                    const int y = UP2 ? (2 * gy + pa) : gy, x = UP2 ? (2 * gx + pb) : gx;
-                    v4f r = v4f{0.f, 0.f, 0.f, 0.f};
-                    if (a.res && (gy < gridH) && (gx < gridW)) {
-                        const size_t rp = a.res_up ? ((size_t)(b * (a.H >> 1) + (y >> 1)) * (a.W >> 1) + (x >> 1))
-                                                   : ((size_t)(b * a.H + y) * a.W + x);
-                        r = *reinterpret_cast<const v4f*>(a.res + rp * a.Cout + co);
-                    }
-                    rsd_all[nt][hb][i] = r;
-                }
-    }
+    }   // !OVL
+
     __syncthreads();   // every wave is done with the patch / weight buffers before they become transpose space
     // ---- epilogue: as conv_mfma.hip -- each wave transposes its 64 x 64 tile through a private 8-KB LDS region so
     //      that every lane moves 16 B; bias, residual and the GroupNorm statistics of the output are applied here.
@@ -385,7 +489,7 @@ __global__ __launch_bounds__(64 * ROWS) void conv_split_kernel(const ConvArgs a)
             v4f ssum = v4f{0.f, 0.f, 0.f, 0.f}, ssq = ssum;
 #pragma unroll
             for (int hb = 0; hb < 2; ++hb) {
-                v4f val[4];
+                v4f val[4], rsd[4];
                 size_t oidx[4];
                 bool ok[4];
 #pragma unroll
@@ -395,12 +499,18 @@ __global__ __launch_bounds__(64 * ROWS) void conv_split_kernel(const ConvArgs a)
                     ok[i] = (gy < gridH) && (gx < gridW);
                     const int y = UP2 ? (2 * gy + pa) : gy, x = UP2 ? (2 * gx + pb) : gx;
                     oidx[i] = ((size_t)(b * a.H + y) * a.W + x) * a.Cout + co;
+                    rsd[i] = v4f{0.f, 0.f, 0.f, 0.f};
+                    if (a.res && ok[i]) {
+                        const size_t rp = a.res_up ? ((size_t)(b * (a.H >> 1) + (y >> 1)) * (a.W >> 1) + (x >> 1))
+                                                   : ((size_t)(b * a.H + y) * a.W + x);
+                        rsd[i] = *reinterpret_cast<const v4f*>(a.res + rp * a.Cout + co);
+                    }
                     val[i] = *reinterpret_cast<const v4f*>(tr + p * 32 + 4 * cq);
                 }
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
                     if (ok[i]) {
-                        const v4f o = val[i] * wsc + bias + rsd_all[nt][hb][i];
+                        const v4f o = val[i] * wsc + bias + rsd[i];
                         *reinterpret_cast<v4f*>(a.out + oidx[i]) = o;
                         ssum += o;
                         ssq += o * o;
@@ -456,7 +566,8 @@ static void launch_split(const ConvArgs& a, hipStream_t stream) {
     const unsigned grid = (unsigned)(a.B * (up2 ? 4 : 1) * tilesX * tilesY * (a.Cout / 128));
     const size_t coef_lds = a.coef ? (size_t)3 * (a.C0 + a.C1) * sizeof(float) : 0;
     auto need = [&](int npix) {
-        const size_t main = (size_t)(npix + 2 * 128) * (4 * NS) * 16 + coef_lds;
+        const int npatch = (NS == 2 && a.taps == 9) ? 2 : 1;       // OVL instantiation: two patch buffers
+        const size_t main = (size_t)(npatch * npix + 2 * 128) * (4 * NS) * 16 + coef_lds;
         const size_t tr = (size_t)ROWS * 2048 * sizeof(float);      // epilogue transpose regions alias the buffers
         return main > tr ? main : tr;
     };

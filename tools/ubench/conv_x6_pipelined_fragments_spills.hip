@@ -1,3 +1,6 @@
+// ARCHIVED EXPERIMENT (not built): conv_x6.hip with the next stage's fragments requested before the per-stage barrier and a
+// three-slot weight ring. Correct, but the two live fragment sets push the 9-tap kernel over 256 VGPRs (560 B of scratch per
+// lane inside the MFMA loop); see DESIGN.md section 4.
 // Fused implicit-GEMM convolution for gfx950 (MI355X): fp32 accuracy on the 16-bit matrix pipe.
 //
 // Same operator as conv_mfma.hip (see there for what is fused and the reference lines it replaces:
@@ -57,14 +60,21 @@ template <> struct SplitT<2> {
 };
 
 #ifdef CDDPM_STAMPS
-// phase accounting for diagnostic builds: 0 prologue, 1 patch stage (barrier + transform + split + ds_write), 2 weight
-// stage (ds_write + prefetch issue + barrier), 3 MFMA compute, 4 fold, 5 epilogue
+// phase accounting for diagnostic builds (waves 0 and 4 = the two waves of SIMD 0): 0 prologue, 1 wait at the chunk
+// barrier, 2 patch transform + split + ds_write, 3 weight ds_write + prefetch issue, 4 wait at the stage barrier,
+// 5 fragment reads + MFMA issue, 6 fold, 7 epilogue
 #define STAMP(i) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); st_[i] += now_ - last_; last_ = now_; }
 #else
 #define STAMP(i)
 #endif
 
 __device__ __forceinline__ float silu_x6(float v) {
+#ifdef CDDPM_SILU_PLAIN
+    // v * sigmoid(v) on v_exp_f32 / v_rcp_f32 (1 ulp each) without the split-product correction of the exponent: the
+    // rounding of t = -v log2(e) costs |t| 2^-24 ln 2 relative in 2^t, i.e. an ABSOLUTE error of silu below 1e-8 everywhere
+    const float tp = fminf(-v * 1.44269502162933349609375f, 126.0f);
+    return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(tp));
+#else
     // identical evaluation to conv_mfma.hip::silu_f (split-product exp2, ~1.5 ulp)
     const float t = fminf(-v * 1.44269502162933349609375f, 126.0f);
     float tl = __builtin_fmaf(-v, 1.44269502162933349609375f, -t);
@@ -73,6 +83,7 @@ __device__ __forceinline__ float silu_x6(float v) {
     float e = __builtin_amdgcn_exp2f(t);
     e = __builtin_fmaf(e, tl * 0.693147180559945f, e);
     return v * __builtin_amdgcn_rcpf(1.0f + e);
+#endif
 }
 
 // split of four fp32 values into NS 16-bit quads (8 B each): t[0] = cvt(v), t[1] = cvt(v - t[0]), ...
@@ -88,7 +99,7 @@ __device__ __forceinline__ void split_x4(const v4f v, typename SplitT<NS>::v4 (&
 }
 
 template <int TAPS, int ROWS, int NS>
-__global__ __launch_bounds__(64 * ROWS) void conv_split_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(64 * ROWS, ROWS == 4 ? 2 : 1) void conv_split_kernel(const ConvArgs a) {
     typedef typename SplitT<NS>::v8 frag;
     constexpr int SP = 4 * NS;                          // 16-B slots per pixel / per cout row
     constexpr int THREADS = 64 * ROWS;
@@ -109,14 +120,15 @@ __global__ __launch_bounds__(64 * ROWS) void conv_split_kernel(const ConvArgs a)
 
     extern __shared__ v4f lds[];
     v4f* ldsA = lds;                    // NPIX * SP slots
-    v4f* ldsW = lds + NPIX * SP;        // 2 * WSLOTS
-    v4f* ldsC = ldsW + 2 * WSLOTS;      // GroupNorm/FiLM coefficients of this sample (3 x Cin floats)
+    constexpr int NWS = (NS == 2) ? 3 : 2;   // weight slab slots: the fp16 form runs the pipelined loop below on a ring of three
+    v4f* ldsW = lds + NPIX * SP;        // NWS * WSLOTS
+    v4f* ldsC = ldsW + NWS * WSLOTS;    // GroupNorm/FiLM coefficients of this sample (3 x Cin floats)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
 #ifdef CDDPM_STAMPS
-    unsigned long long st_[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long last_ = __builtin_amdgcn_s_memtime();
     const unsigned long long t0c_ = last_, t0r_ = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -286,6 +298,133 @@ __global__ __launch_bounds__(64 * ROWS) void conv_split_kernel(const ConvArgs a)
         }
     };
 
+    // fragment fetch / product helpers shared by the pipelined loop
+    auto frag_rows = [&](int tap, int (&arow)[2]) {
+        const int ky = (TAPS == 9) ? (tap / 3) : (UP2 ? (tap >> 1) : 0);
+        const int kx = (TAPS == 9) ? (tap - 3 * ky) : (UP2 ? (tap & 1) : 0);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) arow[mt] = (2 * wm + mt + ky) * PW + li + kx;
+    };
+    auto load_frags = [&](int tap, int slot, int jk, frag (&fa)[NS][2], frag (&fb)[NS][2]) {
+        int arow[2];
+        frag_rows(tap, arow);
+        const v4f* wb = ldsW + slot * WSLOTS;
+        const int u = 2 * jk + lh;
+#pragma unroll
+        for (int sp = 0; sp < NS; ++sp)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                fa[sp][i] = __builtin_bit_cast(frag, ldsA[slot_of(arow[i], sp, u)]);
+                fb[sp][i] = __builtin_bit_cast(frag, wb[slot_of(brow[i], sp, u)]);
+            }
+    };
+    auto products = [&](const frag (&fa)[NS][2], const frag (&fb)[NS][2], bool restart) {
+        const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        constexpr int NP = (NS == 3) ? 6 : 3;
+        constexpr int PA[6] = {NS == 3 ? 2 : 1, 0, 1, 1, 0, 0};
+        constexpr int PB[6] = {0, NS == 3 ? 2 : 1, NS == 3 ? 1 : 0, 0, 1, 0};
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const int sa = (NS == 3) ? PA[p] : (p == 0 ? 1 : 0);
+            const int sb = (NS == 3) ? PB[p] : (p == 1 ? 1 : 0);
+            if (p == 0 && restart) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = SplitT<NS>::mfma(fa[sa][i], fb[sb][j], zero16);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = SplitT<NS>::mfma(fa[sa][i], fb[sb][j], acc[i][j]);
+            }
+        }
+    };
+
+    if constexpr (NS == 2) {
+        // ---- pipelined main loop (fp16 form). One workgroup barrier per stage, at its END; everything a stage reads
+        // after the barrier is already in registers:
+        //   weights: global -> registers one stage ahead -> ring slot (s + 2) % 3 during stage s, so slab s + 1 became
+        //            visible at the barrier that ended stage s - 1;
+        //   fragments of k-step 0 of stage s + 1 (patch + slab s + 1) are requested in the middle of stage s, behind its
+        //            first MFMA group, and land while the second group runs: after the barrier the MFMAs start at once and
+        //            the eight waves' fragment reads no longer arrive at the LDS in one burst.
+        const int total = nch_main * TAPS + nch_skip;
+        auto wslab_at = [&](int gs) -> const v4f* {      // slab of stage gs; past the end it wraps (unconditional prefetch)
+            if (gs >= total) gs = 0;
+            return (gs < nch_main * TAPS) ? (wmain + (size_t)gs * WSLOTS) : (wskip + (size_t)(gs - nch_main * TAPS) * WSLOTS);
+        };
+        auto put_slab = [&](int gs) {                    // registers -> ring slot of stage gs
+#pragma unroll
+            for (int i = 0; i < WK; ++i) ldsW[(gs % NWS) * WSLOTS + tid + THREADS * i] = wreg[i];
+        };
+        auto get_slab = [&](int gs) {                    // global -> registers
+            const v4f* pn = wslab_at(gs);
+#pragma unroll
+            for (int i = 0; i < WK; ++i) wreg[i] = pn[tid + THREADS * i];
+        };
+        get_slab(0);
+        load_act(0);
+        if (have_coef) {
+            const int nq = Cin >> 2;
+            const size_t plane = (size_t)a.B * Cin;
+            for (int i = tid; i < 3 * nq; i += THREADS) {
+                const int pl = i / nq, cq = i - pl * nq;
+                ldsC[i] = *reinterpret_cast<const v4f*>(a.coef + pl * plane + (size_t)b * Cin + 4 * cq);
+            }
+        }
+        __syncthreads();                                 // coefficient cache filled
+        store_act(0);
+        put_slab(0);
+        get_slab(1);
+        __syncthreads();                                 // patch 0 and slab 0 visible
+        put_slab(1);                                     // visible after the barrier that ends stage 0
+        get_slab(2);
+        frag pa[NS][2], pb[NS][2], qa[NS][2], qb[NS][2];
+        load_frags((nch_main > 0) ? 0 : (TAPS / 2), 0, 0, pa, pb);
+        STAMP(0)
+        int gs = 0;
+        for (int chunk = 0; chunk < nch; ++chunk) {
+            const bool main_seg = chunk < nch_main;
+            const int ntap = main_seg ? TAPS : 1;
+            for (int t = 0; t < ntap; ++t, ++gs) {
+                const bool last_tap = (t == ntap - 1);
+                const int tap = main_seg ? t : (TAPS / 2);                 // skip segment: centre tap
+                load_frags(tap, gs % NWS, 1, qa, qb);                       // k-step 1 of this stage
+                __builtin_amdgcn_sched_barrier(0);      // (the barriers pin the phase order: live fragment sets stay at two)
+                products(pa, pb, (t % FOLD) == 0);
+                __builtin_amdgcn_sched_barrier(0);
+                // slab of stage gs + 2 -> the slot stage gs - 1 used (every wave left that stage at the last barrier)
+                if (gs + 2 < total) put_slab(gs + 2);
+                get_slab(gs + 3);
+                __builtin_amdgcn_sched_barrier(0);
+                if (!last_tap) load_frags(tap + 1, (gs + 1) % NWS, 0, pa, pb);   // k-step 0 of the next stage
+                else if (chunk + 1 < nch) load_act(chunk + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                STAMP(3)
+                products(qa, qb, false);
+                __builtin_amdgcn_sched_barrier(0);
+                STAMP(5)
+                if ((t % FOLD) == FOLD - 1 || last_tap) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) tot[i][j] += acc[i][j];
+                    STAMP(6)
+                }
+                __syncthreads();     // stage done: slab gs + 1 visible, slot of stage gs free, (last tap) patch free
+                STAMP(4)
+            }
+            if (chunk + 1 < nch) {
+                store_act(chunk + 1);
+                STAMP(2)
+                __syncthreads();     // next patch visible
+                STAMP(1)
+                const bool nmain = (chunk + 1) < nch_main;
+                load_frags(nmain ? 0 : (TAPS / 2), gs % NWS, 0, pa, pb);
+            }
+        }
+    } else {
     // ---- main loop: weights double-buffered in LDS and prefetched through registers one stage ahead;
     //      the next chunk's patch is fetched into registers behind the last tap's MFMAs.
     {
@@ -308,8 +447,9 @@ __global__ __launch_bounds__(64 * ROWS) void conv_split_kernel(const ConvArgs a)
         const bool main_seg = chunk < nch_main;
         const int ntap = main_seg ? TAPS : 1;
         __syncthreads();   // every wave is done reading the previous patch
-        store_act(chunk);
         STAMP(1)
+        store_act(chunk);
+        STAMP(2)
         for (int t = 0; t < ntap; ++t) {
 #pragma unroll
             for (int i = 0; i < WK; ++i) ldsW[buf * WSLOTS + tid + THREADS * i] = wreg[i];
@@ -318,50 +458,39 @@ __global__ __launch_bounds__(64 * ROWS) void conv_split_kernel(const ConvArgs a)
 #pragma unroll
             for (int i = 0; i < WK; ++i) wreg[i] = pn[tid + THREADS * i];
             if (last_tap && chunk + 1 < nch) load_act(chunk + 1);
+            STAMP(3)
             __syncthreads();
-            STAMP(2)
+            STAMP(4)
             // accumulation in three levels: an MFMA sums 16 products, `acc` collects FOLD taps of a 32-channel chunk
             // (<= 96 products per chain), `tot` sums those groups. The rounding noise of an fp32 chain grows with the
             // magnitude of its partial sums, so short chains folded into a long-lived total keep it near the
             // storage-rounding level (tools/ubench/bf16_split_accuracy.hip, tools/chain_noise.py).
             compute(main_seg ? t : (TAPS / 2), buf, (t % FOLD) == 0);   // skip segment: centre tap
             buf ^= 1;
-            STAMP(3)
+            STAMP(5)
             if ((t % FOLD) == FOLD - 1 || last_tap) {
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) tot[i][j] += acc[i][j];
-                STAMP(4)
+                    for (int j = 0; j < 2; ++j) {
+#ifdef CDDPM_FOLD_ASM    // plain v_add_f32: the compiler otherwise packs the fold into v_pk_add_f32, which issues slower beside MFMAs
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            float tv = tot[i][j][r];
+                            asm volatile("v_add_f32 %0, %0, %1" : "+v"(tv) : "v"(acc[i][j][r]));
+                            tot[i][j][r] = tv;
+                        }
+#else
+                        tot[i][j] += acc[i][j];
+#endif
+                    }
+                STAMP(6)
             }
         }
     }
 
-    // residual tile of this wave (16 x 16 B per lane): requested here, in one go, so that the loads fly while the waves
-    // meet at the barrier and transpose; the accumulator / fragment registers are dead by now. (Loading each batch right
-    // before its add exposed the global latency four times per wave: 12 % of the kernel on the +residual layers.)
-    v4f rsd_all[2][2][4];
-    {
-        const int cq = lane & 7, prow = lane >> 3;
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-            for (int hb = 0; hb < 2; ++hb)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int co = cb * 128 + 64 * wn + 32 * nt + 4 * cq;
-                    const int p = 8 * (4 * hb + i) + prow;
-                    const int gy = y0 + 2 * wm + (p >> 5), gx = x0 + (p & 31);
-                    const int y = UP2 ? (2 * gy + pa) : gy, x = UP2 ? (2 * gx + pb) : gx;
-                    v4f r = v4f{0.f, 0.f, 0.f, 0.f};
-                    if (a.res && (gy < gridH) && (gx < gridW)) {
-                        const size_t rp = a.res_up ? ((size_t)(b * (a.H >> 1) + (y >> 1)) * (a.W >> 1) + (x >> 1))
-                                                   : ((size_t)(b * a.H + y) * a.W + x);
-                        r = *reinterpret_cast<const v4f*>(a.res + rp * a.Cout + co);
-                    }
-                    rsd_all[nt][hb][i] = r;
-                }
-    }
+    }   // NS == 3: barrier-per-stage loop above
+
     __syncthreads();   // every wave is done with the patch / weight buffers before they become transpose space
     // ---- epilogue: as conv_mfma.hip -- each wave transposes its 64 x 64 tile through a private 8-KB LDS region so
     //      that every lane moves 16 B; bias, residual and the GroupNorm statistics of the output are applied here.
@@ -385,7 +514,7 @@ __global__ __launch_bounds__(64 * ROWS) void conv_split_kernel(const ConvArgs a)
             v4f ssum = v4f{0.f, 0.f, 0.f, 0.f}, ssq = ssum;
 #pragma unroll
             for (int hb = 0; hb < 2; ++hb) {
-                v4f val[4];
+                v4f val[4], rsd[4];
                 size_t oidx[4];
                 bool ok[4];
 #pragma unroll
@@ -395,12 +524,18 @@ __global__ __launch_bounds__(64 * ROWS) void conv_split_kernel(const ConvArgs a)
                     ok[i] = (gy < gridH) && (gx < gridW);
                     const int y = UP2 ? (2 * gy + pa) : gy, x = UP2 ? (2 * gx + pb) : gx;
                     oidx[i] = ((size_t)(b * a.H + y) * a.W + x) * a.Cout + co;
+                    rsd[i] = v4f{0.f, 0.f, 0.f, 0.f};
+                    if (a.res && ok[i]) {
+                        const size_t rp = a.res_up ? ((size_t)(b * (a.H >> 1) + (y >> 1)) * (a.W >> 1) + (x >> 1))
+                                                   : ((size_t)(b * a.H + y) * a.W + x);
+                        rsd[i] = *reinterpret_cast<const v4f*>(a.res + rp * a.Cout + co);
+                    }
                     val[i] = *reinterpret_cast<const v4f*>(tr + p * 32 + 4 * cq);
                 }
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
                     if (ok[i]) {
-                        const v4f o = val[i] * wsc + bias + rsd_all[nt][hb][i];
+                        const v4f o = val[i] * wsc + bias + rsd[i];
                         *reinterpret_cast<v4f*>(a.out + oidx[i]) = o;
                         ssum += o;
                         ssq += o * o;
@@ -426,9 +561,9 @@ __global__ __launch_bounds__(64 * ROWS) void conv_split_kernel(const ConvArgs a)
         }
     }
 #ifdef CDDPM_STAMPS
-    STAMP(5)
-    if (a.stamps && lane == 0 && wave < 4) {
-        for (int i = 0; i < 6; ++i) atomicAdd(&a.stamps[wave * 8 + i], st_[i]);
+    STAMP(7)
+    if (a.stamps && lane == 0 && (wave & 3) == 0) {
+        for (int i = 0; i < 8; ++i) atomicAdd(&a.stamps[(wave >> 2) * 8 + i], st_[i]);
         if (wave == 0) {
             atomicAdd(&a.stamps[40], __builtin_amdgcn_s_memtime() - t0c_);
             atomicAdd(&a.stamps[41], __builtin_amdgcn_s_memrealtime() - t0r_);
@@ -447,16 +582,15 @@ int conv_mode() {
     return mode;
 }
 
-template <int NS>
+template <int NS, int ROWS>
 static void launch_split(const ConvArgs& a, hipStream_t stream) {
-    constexpr int ROWS = 8;
     const bool up2 = (a.taps == 4);
     const int gh = up2 ? a.H / 2 : a.H, gw = up2 ? a.W / 2 : a.W;
     const int tilesX = (gw + 31) / 32, tilesY = (gh + ROWS - 1) / ROWS;
     const unsigned grid = (unsigned)(a.B * (up2 ? 4 : 1) * tilesX * tilesY * (a.Cout / 128));
     const size_t coef_lds = a.coef ? (size_t)3 * (a.C0 + a.C1) * sizeof(float) : 0;
     auto need = [&](int npix) {
-        const size_t main = (size_t)(npix + 2 * 128) * (4 * NS) * 16 + coef_lds;
+        const size_t main = (size_t)(npix + (NS == 2 ? 3 : 2) * 128) * (4 * NS) * 16 + coef_lds;
         const size_t tr = (size_t)ROWS * 2048 * sizeof(float);      // epilogue transpose regions alias the buffers
         return main > tr ? main : tr;
     };
@@ -473,8 +607,10 @@ static void launch_split(const ConvArgs& a, hipStream_t stream) {
 }
 
 void launch_conv_split(const ConvArgs& a, hipStream_t stream) {
-    if (conv_mode() == 1) launch_split<3>(a, stream);
-    else launch_split<2>(a, stream);
+    // tile height: 8 rows / 8 waves / one workgroup per CU (default) or CDDPM_SPLIT_ROWS=4: 4 rows / 4 waves / two per CU
+    static const bool rows4 = [] { const char* e = getenv("CDDPM_SPLIT_ROWS"); return e && e[0] == '4'; }();
+    if (conv_mode() == 1) { if (rows4) launch_split<3, 4>(a, stream); else launch_split<3, 8>(a, stream); }
+    else { if (rows4) launch_split<2, 4>(a, stream); else launch_split<2, 8>(a, stream); }
 }
 
 // ---- host side: 16-bit round-to-nearest-even conversions and the splits
