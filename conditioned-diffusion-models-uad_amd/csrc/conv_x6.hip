@@ -28,7 +28,8 @@
 // LDS (one workgroup per CU): per pixel / per cout row SP = 4 NS slots of 16 B (slot = split s, u = channel / 8):
 //   NS = 3: stride 12 slots, slot (s, u) at 4 s + (u ^ ((row >> 2) & 3));  NS = 2: stride 8, (4 s + u) ^ ((row >> 1) & 7)
 //   -> 16 consecutive rows x one slot cover all 16 four-bank groups: ds_read_b128 of a fragment is conflict free.
-//   act patch (8+2) x (32+2) pixels (65 | 43.5 KB) + 2 weight slabs [128 cout][SP] (49 | 32 KB) + coefficient cache;
+//   act patch (8+2) x (32+2) pixels (65 | 43.5 KB) + 2 weight stages (bf16: one slab [128 cout][SP] = 24.6 KB each;
+//   fp16: a row of three taps = 3 x 16 KB each) + coefficient cache;
 //   the packed global weight image (host-split, pack_conv_weights_split) IS the LDS image: staging is a 16-B copy.
 // A lane's 16-B fragment = 8 consecutive channels = its K elements of one k-step (lane>>5 selects the half).
 #include "kernels.h"
@@ -104,13 +105,18 @@ __global__ __launch_bounds__(64 * ROWS) void conv_split_kernel(const ConvArgs a)
 #endif
     constexpr int FOLD = (TAPS == 9) ? CDDPM_X6_FOLD : (TAPS == 4 ? 2 : 1);   // taps per accumulation group
     constexpr int WSLOTS = 128 * SP;                    // 16-B slots of a weight slab
-    constexpr int WK = WSLOTS / THREADS;                // per thread: 3 | 2
+    // taps per weight stage: the fp16 form stages a whole row of taps (3 of the 3x3, 2 of the folded 2x2) per workgroup
+    // barrier -- one barrier (and one burst of fragment reads behind it) per 72 MFMAs of a wave instead of per 24, and the
+    // stage is exactly one accumulation group (FOLD taps). The bf16 form's slabs are 1.5x larger: one tap per stage.
+    constexpr int TPS = (NS == 2) ? FOLD : 1;
+    constexpr int WSTAGE = TPS * WSLOTS;                // 16-B slots of one weight stage
+    constexpr int WK = WSLOTS / THREADS;                // 16-B pieces of ONE slab per thread: 3 | 2
     static_assert(WSLOTS % THREADS == 0, "weight slab must divide evenly");
 
     extern __shared__ v4f lds[];
     v4f* ldsA = lds;                    // NPIX * SP slots
-    v4f* ldsW = lds + NPIX * SP;        // 2 * WSLOTS
-    v4f* ldsC = ldsW + 2 * WSLOTS;      // GroupNorm/FiLM coefficients of this sample (3 x Cin floats)
+    v4f* ldsW = lds + NPIX * SP;        // 2 * WSTAGE
+    v4f* ldsC = ldsW + 2 * WSTAGE;      // GroupNorm/FiLM coefficients of this sample (3 x Cin floats)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -169,7 +175,7 @@ __global__ __launch_bounds__(64 * ROWS) void conv_split_kernel(const ConvArgs a)
     const v4f* wmain = reinterpret_cast<const v4f*>(a.wpk) + (size_t)(cls * ncb + cb) * nch_main * TAPS * WSLOTS;
     const v4f* wskip = reinterpret_cast<const v4f*>(a.skip_wpk) + (size_t)cb * nch_skip * WSLOTS;
 
-    v4f wreg[WK];
+    v4f wreg[TPS * WK];
     v4f areg[NK];
     const bool have_coef = (a.coef != nullptr);
 
@@ -244,14 +250,13 @@ __global__ __launch_bounds__(64 * ROWS) void conv_split_kernel(const ConvArgs a)
     for (int nt = 0; nt < 2; ++nt) brow[nt] = 64 * wn + 32 * nt + li;
 
     // `first`: the accumulators restart here (C = 0 in the first MFMA of each tile, no register clearing)
-    auto compute = [&](int tap, int buf, bool first) {
+    auto compute = [&](int tap, const v4f* wb, bool first) {
         const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         const int ky = (TAPS == 9) ? (tap / 3) : (UP2 ? (tap >> 1) : 0);
         const int kx = (TAPS == 9) ? (tap - 3 * ky) : (UP2 ? (tap & 1) : 0);
         int arow[2];
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) arow[mt] = (2 * wm + mt + ky) * PW + li + kx;
-        const v4f* wb = ldsW + buf * WSLOTS;
         // products kept, smallest first: NS = 3: lh hl mm mh hm hh;  NS = 2: mh hm hh
         constexpr int NP = (NS == 3) ? 6 : 3;
         constexpr int PA[6] = {NS == 3 ? 2 : 1, 0, 1, 1, 0, 0};      // split index of the A term
@@ -286,6 +291,7 @@ __global__ __launch_bounds__(64 * ROWS) void conv_split_kernel(const ConvArgs a)
         }
     };
 
+    if constexpr (TPS == 1) {
     // ---- main loop: weights double-buffered in LDS and prefetched through registers one stage ahead;
     //      the next chunk's patch is fetched into registers behind the last tap's MFMAs.
     {
@@ -324,7 +330,7 @@ __global__ __launch_bounds__(64 * ROWS) void conv_split_kernel(const ConvArgs a)
             // (<= 96 products per chain), `tot` sums those groups. The rounding noise of an fp32 chain grows with the
             // magnitude of its partial sums, so short chains folded into a long-lived total keep it near the
             // storage-rounding level (tools/ubench/bf16_split_accuracy.hip, tools/chain_noise.py).
-            compute(main_seg ? t : (TAPS / 2), buf, (t % FOLD) == 0);   // skip segment: centre tap
+            compute(main_seg ? t : (TAPS / 2), ldsW + buf * WSLOTS, (t % FOLD) == 0);   // skip segment: centre tap
             buf ^= 1;
             STAMP(3)
             if ((t % FOLD) == FOLD - 1 || last_tap) {
@@ -335,6 +341,89 @@ __global__ __launch_bounds__(64 * ROWS) void conv_split_kernel(const ConvArgs a)
                 STAMP(4)
             }
         }
+    }
+
+    } else {
+    // ---- main loop: weight stages (TPS taps of one 32-channel chunk) double-buffered in LDS and prefetched through
+    //      registers one stage ahead; the next chunk's patch is fetched into registers behind the last stage's MFMAs.
+    // stage pointer / slab count; past the end it wraps to stage 0 so that the prefetch stays unconditional
+    auto wstage = [&](int chunk, int st, int& nsl) -> const v4f* {
+        if (chunk >= nch) { chunk = 0; st = 0; }
+        if (chunk < nch_main) { nsl = TPS; return wmain + ((size_t)chunk * TAPS + st * TPS) * WSLOTS; }
+        nsl = 1;
+        return wskip + (size_t)(chunk - nch_main) * WSLOTS;
+    };
+    auto get_stage = [&](const v4f* p, int nsl) {        // global -> registers (nsl slabs of this stage)
+#pragma unroll
+        for (int sl = 0; sl < TPS; ++sl)
+            if (TPS == 1 || sl < nsl) {
+#pragma unroll
+                for (int i = 0; i < WK; ++i) wreg[sl * WK + i] = p[sl * WSLOTS + tid + THREADS * i];
+            }
+    };
+    auto put_stage = [&](int buf, int nsl) {             // registers -> LDS
+#pragma unroll
+        for (int sl = 0; sl < TPS; ++sl)
+            if (TPS == 1 || sl < nsl) {
+#pragma unroll
+                for (int i = 0; i < WK; ++i) ldsW[buf * WSTAGE + sl * WSLOTS + tid + THREADS * i] = wreg[sl * WK + i];
+            }
+    };
+    int nsl_cur = 0;
+    {
+        const v4f* p0 = wstage(0, 0, nsl_cur);
+        get_stage(p0, nsl_cur);
+    }
+    load_act(0);
+    if (have_coef) {
+        const int nq = Cin >> 2;
+        const size_t plane = (size_t)a.B * Cin;
+        for (int i = tid; i < 3 * nq; i += THREADS) {
+            const int pl = i / nq, cq = i - pl * nq;
+            ldsC[i] = *reinterpret_cast<const v4f*>(a.coef + pl * plane + (size_t)b * Cin + 4 * cq);
+        }
+    }
+    int buf = 0;
+    STAMP(0)
+    for (int chunk = 0; chunk < nch; ++chunk) {
+        const bool main_seg = chunk < nch_main;
+        const int nst = main_seg ? TAPS / TPS : 1;       // stages of this chunk
+        __syncthreads();   // every wave is done reading the previous patch
+        store_act(chunk);
+        STAMP(1)
+        for (int st = 0; st < nst; ++st) {
+            put_stage(buf, nsl_cur);
+            const int ntaps = nsl_cur;                    // taps of this stage
+            const bool last_st = (st == nst - 1);
+            int nsl_next = 0;
+            const v4f* pn = last_st ? wstage(chunk + 1, 0, nsl_next) : wstage(chunk, st + 1, nsl_next);
+            get_stage(pn, nsl_next);
+            nsl_cur = nsl_next;
+            if (last_st && chunk + 1 < nch) load_act(chunk + 1);
+            __syncthreads();
+            STAMP(2)
+            // accumulation in three levels: an MFMA sums 16 products, `acc` collects FOLD taps of a 32-channel chunk
+            // (<= 96 products per chain), `tot` sums those groups. The rounding noise of an fp32 chain grows with the
+            // magnitude of its partial sums, so short chains folded into a long-lived total keep it near the
+            // storage-rounding level (tools/ubench/bf16_split_accuracy.hip, tools/chain_noise.py).
+#pragma unroll
+            for (int tt = 0; tt < TPS; ++tt)
+                if (TPS == 1 || tt < ntaps) {
+                    const int t = st * TPS + tt;                                  // tap index inside the chunk
+                    compute(main_seg ? t : (TAPS / 2), ldsW + buf * WSTAGE + tt * WSLOTS, (t % FOLD) == 0);   // skip segment: centre tap
+                }
+            buf ^= 1;
+            STAMP(3)
+            if (((st + 1) * TPS) % FOLD == 0 || last_st) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) tot[i][j] += acc[i][j];
+                STAMP(4)
+            }
+        }
+    }
+
     }
 
     // residual tile of this wave (16 x 16 B per lane): requested here, in one go, so that the loads fly while the waves
@@ -456,7 +545,8 @@ static void launch_split(const ConvArgs& a, hipStream_t stream) {
     const unsigned grid = (unsigned)(a.B * (up2 ? 4 : 1) * tilesX * tilesY * (a.Cout / 128));
     const size_t coef_lds = a.coef ? (size_t)3 * (a.C0 + a.C1) * sizeof(float) : 0;
     auto need = [&](int npix) {
-        const size_t main = (size_t)(npix + 2 * 128) * (4 * NS) * 16 + coef_lds;
+        const int tps = (NS == 2) ? (a.taps == 9 ? 3 : (a.taps == 4 ? 2 : 1)) : 1;     // taps per weight stage (kernel: TPS)
+        const size_t main = (size_t)(npix + 2 * tps * 128) * (4 * NS) * 16 + coef_lds;
         const size_t tr = (size_t)ROWS * 2048 * sizeof(float);      // epilogue transpose regions alias the buffers
         return main > tr ? main : tr;
     };
