@@ -1,0 +1,718 @@
+// ARCHIVED EXPERIMENT (not built; -DCDDPM_OVL2 selects the path): two patch buffers, the next chunk's patch staged during tap 7 --
+// by the first wave of each SIMD before its MFMAs, by the second after them. Parity-green but 200-300 B of scratch per lane in the
+// stage loop, whose reloads serialise the weight prefetch: 2.4x slower. See DESIGN.md section 4.
+// Fused implicit-GEMM convolution for gfx950 (MI355X): fp32 accuracy on the 16-bit matrix pipe.
+//
+// Same operator as conv_mfma.hip (see there for what is fused and the reference lines it replaces:
+// src/models/modules/OpenAI_Unet.py:284-338, :386-394, :118-128, :948), same arguments, same results to fp32
+// rounding. What changes is how a product of two fp32 numbers reaches the accumulator: every fp32 operand is split
+// into a few 16-bit terms whose sum reproduces it to fp32 precision, the partial products are exact in fp32 and the
+// 16-bit MFMA (16x the rate of the fp32 MFMA: 2.5 PFLOP/s vs 157 TFLOP/s dense) accumulates them in fp32.
+//
+//   NS = 2, fp16 (default, CDDPM_CONV=h3):  hi = fp16(x), mid = fp16(x - hi), round-to-nearest: two 11-bit terms,
+//       |x - hi - mid| <= 2^-23 |x| (one fp32 ulp at worst; 75 % of fp32 values are reproduced exactly, rms error
+//       0.73 x 2^-24 |x|) while mid is a normal fp16, i.e. |x| >= 2^-2; below that the error is ABSOLUTE, <= 2^-25.
+//       a*b = hi*hi + hi*mid + mid*hi (+ mid*mid <= 2^-24 |ab|, dropped): 3 MFMAs
+//       (v_mfma_f32_32x32x16_f16) = 3/16 of the fp32-MFMA cost. fp16's exponent range needs care: weights are
+//       pre-scaled by a power of two chosen per convolution so that max|w| lands in [2^13, 2^14) (exact; the epilogue
+//       multiplies by the inverse), activations are used as they are -- after GroupNorm/FiLM/SiLU they are O(1), the
+//       domain is |act| < 65504 (beyond it fp16 overflows to inf and the result is NaN: loud, not silently wrong).
+//   NS = 3, bf16 (CDDPM_CONV=x6): hi, mid, lo = three 8-bit terms, exact over the whole fp32 range;
+//       a*b = hh + hm + mh + mm + hl + lh (+ terms <= 2^-24 |ab|): 6 MFMAs (v_mfma_f32_32x32x16_bf16) = 6/16.
+//
+// Against fp64 (tools/ubench/bf16_split_accuracy.hip, K = 4608, SiLU-distributed activations, folded every 96
+// products): fp16x3 1.9e-7, bf16x6 2.0e-7 of rms(C); the fp32 MFMA chain folded per 288: 3.2e-7; the reference's CPU
+// fmaf chain 1.2e-6. On the whole reverse chain the rounding noise against float64 is below the reference's own
+// (tools/chain_noise.py).
+//
+// GEMM view:  D[pixel][cout] = sum_{tap, ci} act(X)[pixel + tap][ci] * Wt[tap][ci][cout]
+//   M = 256 pixels (8 image rows x 32 columns), N = 128 output channels, K step = 32 input channels x 1 tap
+//   = 2 MFMA k-steps of 16. 8 waves (2 per SIMD), each owns 64 pixels x 64 couts = 2 x 2 MFMA tiles.
+// LDS (one workgroup per CU): per pixel / per cout row SP = 4 NS slots of 16 B (slot = split s, u = channel / 8):
+//   NS = 3: stride 12 slots, slot (s, u) at 4 s + (u ^ ((row >> 2) & 3));  NS = 2: stride 8, (4 s + u) ^ ((row >> 1) & 7)
+//   -> 16 consecutive rows x one slot cover all 16 four-bank groups: ds_read_b128 of a fragment is conflict free.
+//   act patch (8+2) x (32+2) pixels (65 | 43.5 KB) + 2 weight stages (bf16: one slab [128 cout][SP] = 24.6 KB each;
+//   fp16: a row of three taps = 3 x 16 KB each) + coefficient cache;
+//   the packed global weight image (host-split, pack_conv_weights_split) IS the LDS image: staging is a 16-B copy.
+// A lane's 16-B fragment = 8 consecutive channels = its K elements of one k-step (lane>>5 selects the half).
+#include "kernels.h"
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+namespace cddpm {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+template <int NS> struct SplitT;
+template <> struct SplitT<3> {
+    typedef bf16x8 v8; typedef bf16x4 v4;
+    static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+};
+template <> struct SplitT<2> {
+    typedef f16x8 v8; typedef f16x4 v4;
+    static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+};
+
+#ifdef CDDPM_STAMPS
+// phase accounting for diagnostic builds: 0 prologue, 1 patch stage (barrier + transform + split + ds_write), 2 weight
+// stage (ds_write + prefetch issue + barrier), 3 MFMA compute, 4 fold, 5 epilogue
+#define STAMP(i) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); st_[i] += now_ - last_; last_ = now_; }
+#else
+#define STAMP(i)
+#endif
+
+__device__ __forceinline__ float silu_x6(float v) {
+    // identical evaluation to conv_mfma.hip::silu_f (split-product exp2, ~1.5 ulp)
+    const float t = fminf(-v * 1.44269502162933349609375f, 126.0f);
+    float tl = __builtin_fmaf(-v, 1.44269502162933349609375f, -t);
+    tl = __builtin_fmaf(-v, 1.925963033500011e-08f, tl);
+    tl = (t < 126.0f) ? tl : 0.0f;
+    float e = __builtin_amdgcn_exp2f(t);
+    e = __builtin_fmaf(e, tl * 0.693147180559945f, e);
+    return v * __builtin_amdgcn_rcpf(1.0f + e);
+}
+
+// split of four fp32 values into NS 16-bit quads (8 B each): t[0] = cvt(v), t[1] = cvt(v - t[0]), ...
+template <int NS>
+__device__ __forceinline__ void split_x4(const v4f v, typename SplitT<NS>::v4 (&t)[NS]) {
+    typedef typename SplitT<NS>::v4 q4;
+    v4f r = v;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        t[s] = __builtin_convertvector(r, q4);
+        r = r - __builtin_convertvector(t[s], v4f);
+    }
+}
+
+template <int TAPS, int ROWS, int NS>
+__global__ __launch_bounds__(64 * ROWS) void conv_split_kernel(const ConvArgs a) {
+    typedef typename SplitT<NS>::v8 frag;
+    constexpr int SP = 4 * NS;                          // 16-B slots per pixel / per cout row
+    constexpr int THREADS = 64 * ROWS;
+    // TAPS == 4: folded "nearest x2 upsample -> 3x3 conv", one parity class of the output per tile (see conv_mfma.hip)
+    constexpr bool UP2 = (TAPS == 4);
+    constexpr int PAD = (TAPS == 9) ? 1 : 0;
+    constexpr int PW = UP2 ? 33 : 32 + 2 * PAD;         // patch width  (pixels)
+    constexpr int PH = UP2 ? ROWS + 1 : ROWS + 2 * PAD; // patch height (pixels)
+    constexpr int NPIX = PW * PH;                       // 340 | 256 | 297 at ROWS = 8
+    constexpr int NK = (NPIX * 8 + THREADS - 1) / THREADS;   // 16-B (4-channel) patch entries per thread: 6 | 4 | 5
+#ifndef CDDPM_X6_FOLD
+#define CDDPM_X6_FOLD 3
+#endif
+    constexpr int FOLD = (TAPS == 9) ? CDDPM_X6_FOLD : (TAPS == 4 ? 2 : 1);   // taps per accumulation group
+    constexpr int WSLOTS = 128 * SP;                    // 16-B slots of a weight slab
+    // taps per weight stage: the fp16 form stages a whole row of taps (3 of the 3x3, 2 of the folded 2x2) per workgroup
+    // barrier -- one barrier (and one burst of fragment reads behind it) per 72 MFMAs of a wave instead of per 24, and the
+    // stage is exactly one accumulation group (FOLD taps). The bf16 form's slabs are 1.5x larger: one tap per stage.
+#ifdef CDDPM_OVL2
+    // experimental: two patch buffers; the next chunk's patch is staged during tap 7 of a 9-tap chunk, by the first wave of
+    // each SIMD BEFORE its MFMAs and by the second wave AFTER them, so that one wave transforms while the other computes
+    constexpr bool OVL2 = (NS == 2 && TAPS == 9);
+#else
+    constexpr bool OVL2 = false;
+#endif
+    constexpr int TPS = OVL2 ? 1 : ((NS == 2) ? FOLD : 1);
+    constexpr int WSTAGE = TPS * WSLOTS;                // 16-B slots of one weight stage
+    constexpr int WK = WSLOTS / THREADS;                // 16-B pieces of ONE slab per thread: 3 | 2
+    static_assert(WSLOTS % THREADS == 0, "weight slab must divide evenly");
+
+    extern __shared__ v4f lds[];
+    v4f* ldsA = lds;                    // NPIX * SP slots (OVL2: the current one of two)
+    v4f* ldsW = lds + (OVL2 ? 2 : 1) * NPIX * SP;        // 2 * WSTAGE
+    // OVL2: the per-thread source-pixel table lives in LDS (NK ints per thread) instead of registers
+    int* ldsPS = reinterpret_cast<int*>(ldsW + 2 * WSTAGE);
+    v4f* ldsC = ldsW + 2 * WSTAGE + (OVL2 ? (NK * THREADS) / 4 : 0);      // GroupNorm/FiLM coefficients of this sample (3 x Cin floats)
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+#ifdef CDDPM_STAMPS
+    unsigned long long st_[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long last_ = __builtin_amdgcn_s_memtime();
+    const unsigned long long t0c_ = last_, t0r_ = __builtin_amdgcn_s_memrealtime();
+#endif
+    const int li = lane & 31;
+    const int lh = lane >> 5;
+    const int wm = wave % (ROWS / 2);   // pixel rows {2 wm, 2 wm + 1} of the tile
+    const int wn = wave / (ROWS / 2);   // cout half
+
+    const int ncb = a.Cout >> 7;
+    const int gridH = UP2 ? (a.H >> 1) : a.H, gridW = UP2 ? (a.W >> 1) : a.W;
+    const int tilesX = (gridW + 31) >> 5;
+    const int tilesY = (gridH + ROWS - 1) / ROWS;
+    int bid = blockIdx.x;
+    const int cb = bid % ncb;
+    bid /= ncb;
+    const int tx = bid % tilesX;
+    bid /= tilesX;
+    const int ty = bid % tilesY;
+    bid /= tilesY;
+    const int cls = UP2 ? (bid & 3) : 0;
+    const int b = UP2 ? (bid >> 2) : bid;
+    const int pa = cls >> 1, pb = cls & 1;
+    const int y0 = ty * ROWS, x0 = tx * 32;
+
+    // 16-B slot of (row = pixel or cout row, split s, u = channel / 8)
+    auto slot_of = [](int row, int sp, int u) -> int {
+        return (NS == 3) ? (row * 12 + 4 * sp + (u ^ ((row >> 2) & 3))) : (row * 8 + ((4 * sp + u) ^ ((row >> 1) & 7)));
+    };
+
+    const int Cin = a.C0 + a.C1;
+    const int nch_main = Cin >> 5;
+    const int nch_skip = (a.S0 + a.S1) >> 5;
+    const int nch = nch_main + nch_skip;
+
+    // ---- per-thread patch entries: channel quad c4 is fixed per thread, pixel q = (tid>>3) + (THREADS/8) k
+    const int c4 = tid & 7;
+    int psrc[NK];
+    unsigned centre = 0;
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+        const int q = (tid >> 3) + (THREADS / 8) * k;
+        const int pr = q / PW, pc = q - pr * PW;
+        const int y = UP2 ? (y0 + pr + pa - 1) : (y0 + pr - PAD), x = UP2 ? (x0 + pc + pb - 1) : (x0 + pc - PAD);
+        const bool valid = (q < NPIX) && (y >= 0) && (y < gridH) && (x >= 0) && (x < gridW);
+        const int sy = (!UP2 && a.upsample) ? (y >> 1) : y, sx = (!UP2 && a.upsample) ? (x >> 1) : x;
+        psrc[k] = valid ? ((b * a.srcH + sy) * a.srcW + sx) : -1;
+        if (OVL2) ldsPS[k * THREADS + tid] = psrc[k];      // own slot: read back by this thread only, no barrier needed
+        if (valid && (pr >= PAD) && (pr < PH - PAD) && (pc >= PAD) && (pc < PW - PAD)) centre |= 1u << k;
+    }
+
+    const v4f* wmain = reinterpret_cast<const v4f*>(a.wpk) + (size_t)(cls * ncb + cb) * nch_main * TAPS * WSLOTS;
+    const v4f* wskip = reinterpret_cast<const v4f*>(a.skip_wpk) + (size_t)cb * nch_skip * WSLOTS;
+
+    v4f wreg[TPS * WK];
+    v4f areg[NK];
+    const bool have_coef = (a.coef != nullptr);
+
+    auto wslab = [&](int chunk, int tap) -> const v4f* {
+        if (chunk >= nch) { chunk = 0; tap = 0; }      // past the end: wrap, so the prefetch stays unconditional
+        return (chunk < nch_main) ? (wmain + ((size_t)chunk * TAPS + tap) * WSLOTS)
+                                  : (wskip + (size_t)(chunk - nch_main) * WSLOTS);
+    };
+    auto load_act = [&](int chunk) {
+        const float* base;
+        int Cs, c0;
+        const bool main_seg = chunk < nch_main;
+        if (main_seg) {
+            const int ch = chunk << 5;
+            if (ch < a.C0) { base = a.src0; Cs = a.C0; c0 = ch; }
+            else           { base = a.src1; Cs = a.C1; c0 = ch - a.C0; }
+        } else {
+            const int ch = (chunk - nch_main) << 5;
+            if (ch < a.S0) { base = a.skip0; Cs = a.S0; c0 = ch; }
+            else           { base = a.skip1; Cs = a.S1; c0 = ch - a.S0; }
+        }
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+            const int p = (main_seg || ((centre >> k) & 1u)) ? (OVL2 ? ldsPS[k * THREADS + tid] : psrc[k]) : -1;
+            v4f v = v4f{0.f, 0.f, 0.f, 0.f};
+            if (p >= 0) v = *reinterpret_cast<const v4f*>(base + (size_t)p * Cs + c0 + 4 * c4);
+            areg[k] = v;
+        }
+    };
+    auto store_act = [&](int chunk) {
+        const bool main_seg = chunk < nch_main;
+        const bool do_silu = main_seg && a.silu;
+        v4f cm = v4f{0.f, 0.f, 0.f, 0.f}, ca = v4f{1.f, 1.f, 1.f, 1.f}, cd = cm;
+        const bool aff = main_seg && have_coef;
+        if (aff) {
+            const int ci = (chunk << 3) + c4;
+            cm = ldsC[ci];
+            ca = ldsC[(Cin >> 2) + ci];
+            cd = ldsC[2 * (Cin >> 2) + ci];
+        }
+        v2f* dst = reinterpret_cast<v2f*>(ldsA);       // 8-B units
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+            v4f v = areg[k];
+            const int p = (main_seg || ((centre >> k) & 1u)) ? (OVL2 ? ldsPS[k * THREADS + tid] : psrc[k]) : -1;
+            if (p >= 0) {   // zero padding stays exactly zero: the conv pads AFTER the activation
+                if (aff) v = (v - cm) * ca + cd;
+                if (do_silu) { v.x = silu_x6(v.x); v.y = silu_x6(v.y); v.z = silu_x6(v.z); v.w = silu_x6(v.w); }
+            }
+            const int q = (tid >> 3) + (THREADS / 8) * k;
+            if (q < NPIX) {
+                typename SplitT<NS>::v4 t[NS];
+                split_x4<NS>(v, t);
+                // 4 channels = half a slot: slot u = c4 >> 1 of each split, half c4 & 1
+#pragma unroll
+                for (int sp = 0; sp < NS; ++sp) dst[slot_of(q, sp, c4 >> 1) * 2 + (c4 & 1)] = __builtin_bit_cast(v2f, t[sp]);
+            }
+        }
+    };
+
+    f32x16 acc[2][2], tot[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; tot[i][j][r] = 0.f; }
+
+    // B operand (weights) LDS offsets: row j = cout within the 128 block
+    int brow[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) brow[nt] = 64 * wn + 32 * nt + li;
+
+    // `first`: the accumulators restart here (C = 0 in the first MFMA of each tile, no register clearing)
+    auto compute = [&](int tap, const v4f* wb, bool first) {
+        const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const int ky = (TAPS == 9) ? (tap / 3) : (UP2 ? (tap >> 1) : 0);
+        const int kx = (TAPS == 9) ? (tap - 3 * ky) : (UP2 ? (tap & 1) : 0);
+        int arow[2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) arow[mt] = (2 * wm + mt + ky) * PW + li + kx;
+        // products kept, smallest first: NS = 3: lh hl mm mh hm hh;  NS = 2: mh hm hh
+        constexpr int NP = (NS == 3) ? 6 : 3;
+        constexpr int PA[6] = {NS == 3 ? 2 : 1, 0, 1, 1, 0, 0};      // split index of the A term
+        constexpr int PB[6] = {0, NS == 3 ? 2 : 1, NS == 3 ? 1 : 0, 0, 1, 0};
+#pragma unroll
+        for (int jk = 0; jk < 2; ++jk) {
+            const int u = 2 * jk + lh;
+            frag fa[NS][2], fb[NS][2];
+#pragma unroll
+            for (int sp = 0; sp < NS; ++sp)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    fa[sp][i] = __builtin_bit_cast(frag, ldsA[slot_of(arow[i], sp, u)]);
+                    fb[sp][i] = __builtin_bit_cast(frag, wb[slot_of(brow[i], sp, u)]);
+                }
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                const int sa = (NS == 3) ? PA[p] : (p == 0 ? 1 : 0);
+                const int sb = (NS == 3) ? PB[p] : (p == 1 ? 1 : 0);
+                if (jk == 0 && p == 0 && first) {       // uniform branch: restart the chains on an inline C = 0
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) acc[i][j] = SplitT<NS>::mfma(fa[sa][i], fb[sb][j], zero16);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) acc[i][j] = SplitT<NS>::mfma(fa[sa][i], fb[sb][j], acc[i][j]);
+                }
+            }
+        }
+    };
+
+    if constexpr (OVL2) {
+    // ---- main loop: weights double-buffered in LDS and prefetched through registers one stage ahead;
+    //      the next chunk's patch is fetched into registers behind the last tap's MFMAs.
+    {
+        const v4f* p0 = wslab(0, 0);
+#pragma unroll
+        for (int i = 0; i < WK; ++i) wreg[i] = p0[tid + THREADS * i];
+    }
+    load_act(0);
+    if (have_coef) {
+        const int nq = Cin >> 2;
+        const size_t plane = (size_t)a.B * Cin;
+        for (int i = tid; i < 3 * nq; i += THREADS) {
+            const int pl = i / nq, cq = i - pl * nq;
+            ldsC[i] = *reinterpret_cast<const v4f*>(a.coef + pl * plane + (size_t)b * Cin + 4 * cq);
+        }
+    }
+    int buf = 0;
+    STAMP(0)
+    for (int chunk = 0; chunk < nch; ++chunk) {
+        const bool main_seg = chunk < nch_main;
+        const int ntap = main_seg ? TAPS : 1;
+        v4f* const pcur = (OVL2 && (chunk & 1)) ? lds + NPIX * SP : lds;
+        v4f* const pnxt = (OVL2 && !(chunk & 1)) ? lds + NPIX * SP : lds;
+        const bool early = OVL2 && main_seg && (chunk + 1 < nch);      // next patch staged during tap 7
+        if (!OVL2 || chunk == 0) {
+            __syncthreads();   // every wave is done reading the previous patch (OVL2: coefficient cache filled)
+            store_act(chunk);
+        }
+        ldsA = pcur;
+        STAMP(1)
+        for (int t = 0; t < ntap; ++t) {
+#pragma unroll
+            for (int i = 0; i < WK; ++i) ldsW[buf * WSLOTS + tid + THREADS * i] = wreg[i];
+            const bool last_tap = (t == ntap - 1);
+            const v4f* pn = last_tap ? wslab(chunk + 1, 0) : wslab(chunk, t + 1);
+#pragma unroll
+            for (int i = 0; i < WK; ++i) wreg[i] = pn[tid + THREADS * i];
+            if (early ? (t == ntap - 3) : (last_tap && chunk + 1 < nch)) load_act(chunk + 1);
+            __syncthreads();
+            STAMP(2)
+            // OVL2: where the next patch gets staged -- before this stage's MFMAs (first wave of each SIMD at tap 7), after
+            // them (second wave at tap 7; every wave behind the only stage of a 1-tap chunk), or not in this stage
+            const bool stage_here = OVL2 && (chunk + 1 < nch) && (early ? (t == ntap - 2) : last_tap);
+            const bool pre = stage_here && early && (wave < ROWS / 2);
+            const bool post = stage_here && !pre;
+#pragma unroll 1
+            for (int it = 0; it < (OVL2 ? 2 : 1); ++it) {
+                if (OVL2 && ((it == 0) ? pre : post)) { ldsA = pnxt; store_act(chunk + 1); ldsA = pcur; }
+                if (it == 1) break;
+            // accumulation in three levels: an MFMA sums 16 products, `acc` collects FOLD taps of a 32-channel chunk
+            // (<= 96 products per chain), `tot` sums those groups. The rounding noise of an fp32 chain grows with the
+            // magnitude of its partial sums, so short chains folded into a long-lived total keep it near the
+            // storage-rounding level (tools/ubench/bf16_split_accuracy.hip, tools/chain_noise.py).
+            compute(main_seg ? t : (TAPS / 2), ldsW + buf * WSLOTS, (t % FOLD) == 0);   // skip segment: centre tap
+            }
+            buf ^= 1;
+            STAMP(3)
+            if ((t % FOLD) == FOLD - 1 || last_tap) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) tot[i][j] += acc[i][j];
+                STAMP(4)
+            }
+        }
+    }
+
+    } else if constexpr (TPS == 1) {
+    // ---- main loop: weights double-buffered in LDS and prefetched through registers one stage ahead;
+    //      the next chunk's patch is fetched into registers behind the last tap's MFMAs.
+    {
+        const v4f* p0 = wslab(0, 0);
+#pragma unroll
+        for (int i = 0; i < WK; ++i) wreg[i] = p0[tid + THREADS * i];
+    }
+    load_act(0);
+    if (have_coef) {
+        const int nq = Cin >> 2;
+        const size_t plane = (size_t)a.B * Cin;
+        for (int i = tid; i < 3 * nq; i += THREADS) {
+            const int pl = i / nq, cq = i - pl * nq;
+            ldsC[i] = *reinterpret_cast<const v4f*>(a.coef + pl * plane + (size_t)b * Cin + 4 * cq);
+        }
+    }
+    int buf = 0;
+    STAMP(0)
+    for (int chunk = 0; chunk < nch; ++chunk) {
+        const bool main_seg = chunk < nch_main;
+        const int ntap = main_seg ? TAPS : 1;
+        __syncthreads();   // every wave is done reading the previous patch
+        store_act(chunk);
+        STAMP(1)
+        for (int t = 0; t < ntap; ++t) {
+#pragma unroll
+            for (int i = 0; i < WK; ++i) ldsW[buf * WSLOTS + tid + THREADS * i] = wreg[i];
+            const bool last_tap = (t == ntap - 1);
+            const v4f* pn = last_tap ? wslab(chunk + 1, 0) : wslab(chunk, t + 1);
+#pragma unroll
+            for (int i = 0; i < WK; ++i) wreg[i] = pn[tid + THREADS * i];
+            if (last_tap && chunk + 1 < nch) load_act(chunk + 1);
+            __syncthreads();
+            STAMP(2)
+            // accumulation in three levels: an MFMA sums 16 products, `acc` collects FOLD taps of a 32-channel chunk
+            // (<= 96 products per chain), `tot` sums those groups. The rounding noise of an fp32 chain grows with the
+            // magnitude of its partial sums, so short chains folded into a long-lived total keep it near the
+            // storage-rounding level (tools/ubench/bf16_split_accuracy.hip, tools/chain_noise.py).
+            compute(main_seg ? t : (TAPS / 2), ldsW + buf * WSLOTS, (t % FOLD) == 0);   // skip segment: centre tap
+            buf ^= 1;
+            STAMP(3)
+            if ((t % FOLD) == FOLD - 1 || last_tap) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) tot[i][j] += acc[i][j];
+                STAMP(4)
+            }
+        }
+    }
+
+    } else {
+    // ---- main loop: weight stages (TPS taps of one 32-channel chunk) double-buffered in LDS and prefetched through
+    //      registers one stage ahead; the next chunk's patch is fetched into registers behind the last stage's MFMAs.
+    // stage pointer / slab count; past the end it wraps to stage 0 so that the prefetch stays unconditional
+    auto wstage = [&](int chunk, int st, int& nsl) -> const v4f* {
+        if (chunk >= nch) { chunk = 0; st = 0; }
+        if (chunk < nch_main) { nsl = TPS; return wmain + ((size_t)chunk * TAPS + st * TPS) * WSLOTS; }
+        nsl = 1;
+        return wskip + (size_t)(chunk - nch_main) * WSLOTS;
+    };
+    auto get_stage = [&](const v4f* p, int nsl) {        // global -> registers (nsl slabs of this stage)
+#pragma unroll
+        for (int sl = 0; sl < TPS; ++sl)
+            if (TPS == 1 || sl < nsl) {
+#pragma unroll
+                for (int i = 0; i < WK; ++i) wreg[sl * WK + i] = p[sl * WSLOTS + tid + THREADS * i];
+            }
+    };
+    auto put_stage = [&](int buf, int nsl) {             // registers -> LDS
+#pragma unroll
+        for (int sl = 0; sl < TPS; ++sl)
+            if (TPS == 1 || sl < nsl) {
+#pragma unroll
+                for (int i = 0; i < WK; ++i) ldsW[buf * WSTAGE + sl * WSLOTS + tid + THREADS * i] = wreg[sl * WK + i];
+            }
+    };
+    int nsl_cur = 0;
+    {
+        const v4f* p0 = wstage(0, 0, nsl_cur);
+        get_stage(p0, nsl_cur);
+    }
+    load_act(0);
+    if (have_coef) {
+        const int nq = Cin >> 2;
+        const size_t plane = (size_t)a.B * Cin;
+        for (int i = tid; i < 3 * nq; i += THREADS) {
+            const int pl = i / nq, cq = i - pl * nq;
+            ldsC[i] = *reinterpret_cast<const v4f*>(a.coef + pl * plane + (size_t)b * Cin + 4 * cq);
+        }
+    }
+    int buf = 0;
+    STAMP(0)
+    for (int chunk = 0; chunk < nch; ++chunk) {
+        const bool main_seg = chunk < nch_main;
+        const int nst = main_seg ? TAPS / TPS : 1;       // stages of this chunk
+        __syncthreads();   // every wave is done reading the previous patch
+        store_act(chunk);
+        STAMP(1)
+        for (int st = 0; st < nst; ++st) {
+            put_stage(buf, nsl_cur);
+            const int ntaps = nsl_cur;                    // taps of this stage
+            const bool last_st = (st == nst - 1);
+            int nsl_next = 0;
+            const v4f* pn = last_st ? wstage(chunk + 1, 0, nsl_next) : wstage(chunk, st + 1, nsl_next);
+            get_stage(pn, nsl_next);
+            nsl_cur = nsl_next;
+            if (last_st && chunk + 1 < nch) load_act(chunk + 1);
+            __syncthreads();
+            STAMP(2)
+            // accumulation in three levels: an MFMA sums 16 products, `acc` collects FOLD taps of a 32-channel chunk
+            // (<= 96 products per chain), `tot` sums those groups. The rounding noise of an fp32 chain grows with the
+            // magnitude of its partial sums, so short chains folded into a long-lived total keep it near the
+            // storage-rounding level (tools/ubench/bf16_split_accuracy.hip, tools/chain_noise.py).
+#pragma unroll
+            for (int tt = 0; tt < TPS; ++tt)
+                if (TPS == 1 || tt < ntaps) {
+                    const int t = st * TPS + tt;                                  // tap index inside the chunk
+                    compute(main_seg ? t : (TAPS / 2), ldsW + buf * WSTAGE + tt * WSLOTS, (t % FOLD) == 0);   // skip segment: centre tap
+                }
+            buf ^= 1;
+            STAMP(3)
+            if (((st + 1) * TPS) % FOLD == 0 || last_st) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) tot[i][j] += acc[i][j];
+                STAMP(4)
+            }
+        }
+    }
+
+    }
+
+    // residual tile of this wave (16 x 16 B per lane): requested here, in one go, so that the loads fly while the waves
+    // meet at the barrier and transpose; the accumulator / fragment registers are dead by now. (Loading each batch right
+    // before its add exposed the global latency four times per wave: 12 % of the kernel on the +residual layers.)
+    v4f rsd_all[2][2][4];
+    {
+        const int cq = lane & 7, prow = lane >> 3;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int co = cb * 128 + 64 * wn + 32 * nt + 4 * cq;
+                    const int p = 8 * (4 * hb + i) + prow;
+                    const int gy = y0 + 2 * wm + (p >> 5), gx = x0 + (p & 31);
+                    const int y = UP2 ? (2 * gy + pa) : gy, x = UP2 ? (2 * gx + pb) : gx;
+                    v4f r = v4f{0.f, 0.f, 0.f, 0.f};
+                    if (a.res && (gy < gridH) && (gx < gridW)) {
+                        const size_t rp = a.res_up ? ((size_t)(b * (a.H >> 1) + (y >> 1)) * (a.W >> 1) + (x >> 1))
+                                                   : ((size_t)(b * a.H + y) * a.W + x);
+                        r = *reinterpret_cast<const v4f*>(a.res + rp * a.Cout + co);
+                    }
+                    rsd_all[nt][hb][i] = r;
+                }
+    }
+    __syncthreads();   // every wave is done with the patch / weight buffers before they become transpose space
+    // ---- epilogue: as conv_mfma.hip -- each wave transposes its 64 x 64 tile through a private 8-KB LDS region so
+    //      that every lane moves 16 B; bias, residual and the GroupNorm statistics of the output are applied here.
+    {
+        float* tr = reinterpret_cast<float*>(lds) + wave * 2048;      // [64 pixels][32 channels]
+        const int cq = lane & 7;
+        const int prow = lane >> 3;
+        const int tilesY4 = (gridH + 3) >> 2;                         // statistics records are per 4-row band (kernels.h)
+        const int ty4 = (y0 >> 2) + (wm >> 1);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int co = cb * 128 + 64 * wn + 32 * nt + 4 * cq;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    tr[(mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * 32 + li] = tot[mt][nt][r];
+            __builtin_amdgcn_wave_barrier();
+            const v4f bias = a.bias ? *reinterpret_cast<const v4f*>(a.bias + co) : v4f{0.f, 0.f, 0.f, 0.f};
+            const float wsc = (NS == 2) ? a.wscale_inv : 1.0f;      // fp16 weights were pre-scaled by a power of two
+            v4f ssum = v4f{0.f, 0.f, 0.f, 0.f}, ssq = ssum;
+#pragma unroll
+            for (int hb = 0; hb < 2; ++hb) {
+                v4f val[4];
+                size_t oidx[4];
+                bool ok[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int p = 8 * (4 * hb + i) + prow;
+                    const int gy = y0 + 2 * wm + (p >> 5), gx = x0 + (p & 31);
+                    ok[i] = (gy < gridH) && (gx < gridW);
+                    const int y = UP2 ? (2 * gy + pa) : gy, x = UP2 ? (2 * gx + pb) : gx;
+                    oidx[i] = ((size_t)(b * a.H + y) * a.W + x) * a.Cout + co;
+                    val[i] = *reinterpret_cast<const v4f*>(tr + p * 32 + 4 * cq);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (ok[i]) {
+                        const v4f o = val[i] * wsc + bias + rsd_all[nt][hb][i];
+                        *reinterpret_cast<v4f*>(a.out + oidx[i]) = o;
+                        ssum += o;
+                        ssq += o * o;
+                    }
+            }
+            if (a.stats) {
+#pragma unroll
+                for (int m = 8; m < 64; m <<= 1) {
+                    ssum.x += __shfl_xor(ssum.x, m, 64); ssum.y += __shfl_xor(ssum.y, m, 64);
+                    ssum.z += __shfl_xor(ssum.z, m, 64); ssum.w += __shfl_xor(ssum.w, m, 64);
+                    ssq.x += __shfl_xor(ssq.x, m, 64); ssq.y += __shfl_xor(ssq.y, m, 64);
+                    ssq.z += __shfl_xor(ssq.z, m, 64); ssq.w += __shfl_xor(ssq.w, m, 64);
+                }
+                if (prow == 0 && ty4 < tilesY4) {
+                    const int nrec = (UP2 ? 8 : 2) * tilesX * tilesY4;
+                    const int rec = 2 * ((cls * tilesY4 + ty4) * tilesX + tx) + (wm & 1);
+                    float* o = a.stats + (((size_t)b * nrec + rec) * a.Cout + co) * 2;
+                    *reinterpret_cast<v4f*>(o) = v4f{ssum.x, ssq.x, ssum.y, ssq.y};
+                    *reinterpret_cast<v4f*>(o + 4) = v4f{ssum.z, ssq.z, ssum.w, ssq.w};
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+#ifdef CDDPM_STAMPS
+    STAMP(5)
+    if (a.stamps && lane == 0 && wave < 4) {
+        for (int i = 0; i < 6; ++i) atomicAdd(&a.stamps[wave * 8 + i], st_[i]);
+        if (wave == 0) {
+            atomicAdd(&a.stamps[40], __builtin_amdgcn_s_memtime() - t0c_);
+            atomicAdd(&a.stamps[41], __builtin_amdgcn_s_memrealtime() - t0r_);
+        }
+    }
+#endif
+}
+
+int conv_mode() {
+    static const int mode = [] {
+        const char* e = getenv("CDDPM_CONV");
+        if (e && strcmp(e, "f32") == 0) return 0;
+        if (e && strcmp(e, "x6") == 0) return 1;
+        return 2;                                   // "h3" / unset: fp16 two-term split, three products
+    }();
+    return mode;
+}
+
+template <int NS>
+static void launch_split(const ConvArgs& a, hipStream_t stream) {
+    constexpr int ROWS = 8;
+    const bool up2 = (a.taps == 4);
+    const int gh = up2 ? a.H / 2 : a.H, gw = up2 ? a.W / 2 : a.W;
+    const int tilesX = (gw + 31) / 32, tilesY = (gh + ROWS - 1) / ROWS;
+    const unsigned grid = (unsigned)(a.B * (up2 ? 4 : 1) * tilesX * tilesY * (a.Cout / 128));
+    const size_t coef_lds = a.coef ? (size_t)3 * (a.C0 + a.C1) * sizeof(float) : 0;
+    auto need = [&](int npix) {
+#ifdef CDDPM_OVL2
+        const bool ovl2 = (NS == 2 && a.taps == 9);
+#else
+        const bool ovl2 = false;
+#endif
+        const int tps = ovl2 ? 1 : ((NS == 2) ? (a.taps == 9 ? 3 : (a.taps == 4 ? 2 : 1)) : 1);     // taps per weight stage (kernel: TPS)
+        const size_t main = (size_t)((ovl2 ? 2 : 1) * npix + 2 * tps * 128) * (4 * NS) * 16 + coef_lds
+                            + (ovl2 ? (size_t)((npix * 8 + 64 * ROWS - 1) / (64 * ROWS)) * 64 * ROWS * 4 : 0);     // + source-pixel table
+        const size_t tr = (size_t)ROWS * 2048 * sizeof(float);      // epilogue transpose regions alias the buffers
+        return main > tr ? main : tr;
+    };
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_split_kernel<9, ROWS, NS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_split_kernel<1, ROWS, NS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_split_kernel<4, ROWS, NS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr = true;
+    }
+    if (a.taps == 9) hipLaunchKernelGGL((conv_split_kernel<9, ROWS, NS>), dim3(grid), dim3(64 * ROWS), need((ROWS + 2) * 34), stream, a);
+    else if (a.taps == 1) hipLaunchKernelGGL((conv_split_kernel<1, ROWS, NS>), dim3(grid), dim3(64 * ROWS), need(ROWS * 32), stream, a);
+    else hipLaunchKernelGGL((conv_split_kernel<4, ROWS, NS>), dim3(grid), dim3(64 * ROWS), need((ROWS + 1) * 33), stream, a);
+}
+
+void launch_conv_split(const ConvArgs& a, hipStream_t stream) {
+    if (conv_mode() == 1) launch_split<3>(a, stream);
+    else launch_split<2>(a, stream);
+}
+
+// ---- host side: 16-bit round-to-nearest-even conversions and the splits
+static inline uint16_t bf16_rne(float x) {
+    uint32_t u;
+    memcpy(&u, &x, 4);
+    if ((u & 0x7f800000u) == 0x7f800000u) return (uint16_t)(u >> 16);     // inf / nan: truncate (weights are finite)
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+static inline float bf16_to_f(uint16_t h) {
+    const uint32_t u = (uint32_t)h << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+static inline uint16_t f16_rne(float x) { const _Float16 h = (_Float16)x; uint16_t b; memcpy(&b, &h, 2); return b; }   // compiler RNE, subnormals kept
+static inline float f16_to_f(uint16_t b) { _Float16 h; memcpy(&h, &b, 2); return (float)h; }
+
+// power-of-two pre-scale of a weight tensor for the fp16 split: the largest e in [0, 24] with max|w| * 2^e < 2^14
+int conv_weight_exp(const float* w, size_t n) {
+    if (conv_mode() != 2) return 0;
+    float mx = 0.f;
+    for (size_t i = 0; i < n; ++i) { const float v = w[i] < 0 ? -w[i] : w[i]; if (v > mx) mx = v; }
+    int e = 24;
+    while (e > 0 && ldexpf(mx, e) >= 16384.0f) --e;
+    return e;
+}
+
+// w: PyTorch [Cout][Cin][k][k] (taps = k*k) -> [Cout/128][Cin/32][taps][128 rows][4 NS slots][8 x 16 bit]
+//   NS = 3 (bf16): slot (split s, u = channel/8 in the chunk) of row j at 4 s + (u ^ ((j>>2)&3)); 6 bytes per weight
+//   NS = 2 (fp16): w * 2^wexp is split; slot at (4 s + u) ^ ((j>>1)&7); 4 bytes per weight
+void pack_conv_weights_split(const float* w, int Cout, int Cin, int taps, void* dst_, int wexp) {
+    uint16_t* dst = static_cast<uint16_t*>(dst_);
+    const int ncb = Cout / 128, nch = Cin / 32;
+    const int ns = (conv_mode() == 1) ? 3 : 2, sp = 4 * ns;
+    for (int cb = 0; cb < ncb; ++cb)
+        for (int ch = 0; ch < nch; ++ch)
+            for (int t = 0; t < taps; ++t) {
+                uint16_t* img = dst + (((size_t)cb * nch + ch) * taps + t) * (128 * sp * 8);
+                for (int j = 0; j < 128; ++j)
+                    for (int u = 0; u < 4; ++u)
+                        for (int e = 0; e < 8; ++e) {
+                            const int co = cb * 128 + j, ci = ch * 32 + 8 * u + e;
+                            float r = w[((size_t)co * Cin + ci) * taps + t];
+                            if (ns == 3) {
+                                for (int s3 = 0; s3 < 3; ++s3) {
+                                    const uint16_t q = bf16_rne(r);
+                                    r -= bf16_to_f(q);
+                                    img[(size_t)(j * 12 + 4 * s3 + (u ^ ((j >> 2) & 3))) * 8 + e] = q;
+                                }
+                            } else {
+                                r = ldexpf(r, wexp);
+                                for (int s2 = 0; s2 < 2; ++s2) {
+                                    const uint16_t q = f16_rne(r);
+                                    r -= f16_to_f(q);
+                                    img[(size_t)(j * 8 + ((4 * s2 + u) ^ ((j >> 1) & 7))) * 8 + e] = q;
+                                }
+                            }
+                        }
+            }
+}
+
+}  // namespace cddpm
