@@ -17,7 +17,7 @@ Differences, on purpose:
     never assigns it, so its own p_sample crashes; this is the intended semantics (experiment yaml :31);
   * the simplex branch (`noise is not None`, :441-443, :450-452) draws its fields on the device (csrc/simplex.hip,
     bit-exact with the reference's CPU generator for a given seed) instead of numba + host->device copies per step;
-    `box` in-painting is outside the accelerated path and raises NotImplementedError;
+    `box` in-painting is outside the accelerated path and raises NotImplementedError; DDIM (`ddim_sample`) is accelerated;
   * noise: x_T and z_t come from the counter RNG (synth.py / on-device Philox) seeded from torch's global
     generator, so `torch.manual_seed` still makes runs reproducible; pass `seed=`/`slice0=` to pin them.
 """
@@ -172,17 +172,68 @@ class GaussianDiffusion(nn.Module):
             x_T = eng.noise_fill(B, H, W, seed=seed, stream_id=_synth.STREAM_XT, slice0=slice0)
         return eng.reverse(x_T, cond.float() if cond is not None else None, T, noise=z_noise, seed=seed, slice0=slice0)
 
+    def ddim_time_pairs(self, start_t=0):
+        """(time, time_next) pairs of ddim_sample (cond_DDPM.py:468-474): sampling_timesteps + 1 ints from
+        linspace(0, T', sampling_timesteps + 2)[:-1], reversed; T' = start_t or num_timesteps."""
+        total = self.num_timesteps if start_t == 0 else int(start_t)
+        times = torch.linspace(0., total, steps=self.sampling_timesteps + 2)[:-1]
+        times = list(reversed(times.int().tolist()))
+        return list(zip(times[:-1], times[1:]))
+
+    def ddim_coefficients(self, time, time_next, eta=None):
+        """sqrt(alpha_next), c, sigma of one DDIM update in the reference's fp32 tensor arithmetic (:489-499)"""
+        eta = self.ddim_sampling_eta if eta is None else eta
+        acp = self.alphas_cumprod_prev.detach().float().cpu()
+        alpha, alpha_next = acp[time], acp[time_next]
+        sigma = eta * ((1 - alpha / alpha_next) * (1 - alpha_next) / (1 - alpha)).sqrt()
+        c = ((1 - alpha_next) - sigma ** 2).sqrt()
+        return float(alpha_next.sqrt()), float(c), float(sigma)
+
     @torch.no_grad()
-    def ddim_sample(self, *a, **k):
-        raise NotImplementedError("DDIM sampling (cond_DDPM.py:466-515) is outside the accelerated path "
-                                  "(sampling_timesteps == timesteps in the cDDPM experiment)")
+    def ddim_sample(self, shape, clip_denoised=True, cond=None, cond_scale=1., x_start=None, start_t=0, noise=None, *,
+                    x_T=None, z_noise=None, seed=None, slice0=0, device=None):
+        """DDIM sampling (cond_DDPM.py:466-515) over sampling_timesteps + 1 time pairs, one UNet call per pair.
+        Gaussian branch; start_t != 0 starts from q_sample(x_start, t = start_t, x_T) as the reference does (:482).
+        Extras: x_T (the initial N(0,1) draw), z_noise (dict time -> [B,1,H,W] or a [num_timesteps,B,1,H,W] tensor indexed
+        by `time`) inject given draws; otherwise the device Philox is keyed by (seed, time, slice0 + b)."""
+        if not clip_denoised:
+            raise NotImplementedError("clip_denoised=False is not part of the reconstruction path")
+        if noise is not None:
+            raise NotImplementedError("DDIM with simplex noise (cond_DDPM.py:477, :502) is not accelerated")
+        B, _c, H, W = shape
+        dev = torch.device(device) if device is not None else (cond.device if cond is not None else self.betas.device)
+        eng = self._engine(B, H, W, dev)
+        seed = self._draw_seed(seed)
+        pairs = self.ddim_time_pairs(start_t)
+        if x_T is None:
+            x_T = eng.noise_fill(B, H, W, seed=seed, stream_id=_synth.STREAM_XT, slice0=slice0)
+        img = x_T.to(dev).float().contiguous().clone()
+        if start_t != 0:
+            if x_start is None:
+                raise ValueError("ddim_sample with start_t != 0 needs x_start")
+            tT = torch.full((B,), int(start_t), device=dev, dtype=torch.long)
+            xs = x_start.to(dev).float()
+            img = (_extract(self.sqrt_alphas_cumprod, tT, xs.shape) * xs
+                   + _extract(self.sqrt_one_minus_alphas_cumprod, tT, xs.shape) * img)[:, 0].unsqueeze(1).contiguous()
+        eng.prepare_cond(cond.float() if cond is not None else None, B)
+        for i, (time, time_next) in enumerate(pairs):
+            ca, c, sigma = self.ddim_coefficients(time, time_next)
+            z = None
+            if z_noise is not None and time_next > 0:
+                z = z_noise[time]
+            eng.ddim_step(img, time, ca, c, sigma, add_noise=time_next > 0, finalize=(i == len(pairs) - 1),
+                          z=z.to(dev).float().contiguous() if z is not None else None, seed=seed, slice0=slice0)
+        return img
 
     @torch.no_grad()
     def sample(self, batch_size=16, cond=None, cond_scale=1., box=None, x_start=None, start_t=0, noise=None, **kw):
         """(cond_DDPM.py:517-530) image_size may be an int or an (H, W) pair, as DDPM_2D passes it."""
         hw = self.image_size if isinstance(self.image_size, (tuple, list)) else (self.image_size, self.image_size)
         if self.is_ddim_sampling:
-            return self.ddim_sample()
+            if box is not None:
+                raise NotImplementedError("box in-painting (ddim_sample_box is undefined in the reference, :527)")
+            return self.ddim_sample((batch_size, self.channels, int(hw[0]), int(hw[1])), cond=cond, cond_scale=cond_scale,
+                                    x_start=x_start, start_t=start_t, noise=noise, **kw)
         return self.p_sample_loop((batch_size, self.channels, int(hw[0]), int(hw[1])), cond=cond, cond_scale=cond_scale,
                                   box=box, start_t=start_t, noise=noise, x_start=x_start, **kw)
 

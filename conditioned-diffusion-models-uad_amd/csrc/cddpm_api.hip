@@ -899,6 +899,29 @@ int cddpm_p_sample(cddpm_handle h, float* img, const float* z_dev, uint64_t seed
     return 0;
 }
 
+int cddpm_ddim_step(cddpm_handle h, float* img, const float* z_dev, uint64_t seed, uint64_t slice0, int t, float coef_x0,
+                    float coef_eps, float sigma, int add_noise, int finalize, int B, int H, int W, void* stream) {
+    if (check_call(h, B, H, W)) return -1;
+    if (!img) return fail(h, "img_inout_dev is NULL");
+    if (t < 0 || t >= h->d.timesteps) return fail(h, "t=%d outside [0, %d)", t, h->d.timesteps);
+    if (!(coef_x0 == coef_x0) || !(coef_eps == coef_eps) || !(sigma == sigma))
+        return fail(h, "cddpm_ddim_step: NaN coefficient (time pair outside the schedule?)");
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHECK(h, hipSetDevice(h->device));
+    launch_fill_int(h->d_t, B, t, s);
+    if (forward_impl(h, img, h->model_out, B, H, W, s)) return -1;
+    DdimArgs a;
+    a.x = img; a.model_out = h->model_out; a.t_dev = h->d_t;
+    a.sqrt_recip = h->sched[3]; a.sqrt_recipm1 = h->sched[4];
+    a.objective = h->objective;
+    a.coef_x0 = coef_x0; a.coef_eps = coef_eps; a.sigma = sigma; a.add_noise = add_noise ? 1 : 0;
+    a.noise = z_dev; a.seed = seed; a.slice0 = slice0;
+    a.B = B; a.HW = H * W; a.finalize = finalize ? 1 : 0;
+    launch_ddim_step(a, s);
+    HIPCHECK(h, hipGetLastError());
+    return 0;
+}
+
 int cddpm_reverse(cddpm_handle h, float* img, const float* noise_dev, uint64_t seed, uint64_t slice0, int t_start, int B,
                   int H, int W, void* stream) {
     if (check_call(h, B, H, W)) return -1;

@@ -105,6 +105,20 @@ struct StepArgs {
     int finalize;                // 1: also map to [0,1]: (x+1)/2 (cond_DDPM.py:463)
 };
 void launch_step(const StepArgs& a, hipStream_t stream);
+// DDIM step (cond_DDPM.py:487-511): eps = (sqrt_recip[t] x - x0) / sqrt_recipm1[t] from the UNCLIPPED x0 (pred_x0 objective;
+// pred_noise: eps = model output, x0 = sqrt_recip[t] x - sqrt_recipm1[t] eps), x0 clamped to [-1,1], then
+// x <- x0 * coef_x0 + coef_eps * eps + sigma * z   (z only when add_noise)
+struct DdimArgs {
+    float* x; const float* model_out; const int* t_dev; const float* sqrt_recip; const float* sqrt_recipm1;
+    int objective;
+    float coef_x0, coef_eps, sigma;   // sqrt(alpha_next), sqrt(1 - alpha_next - sigma^2), sigma: computed by the caller in fp32
+    int add_noise;                    // time_next > 0
+    const float* noise;               // explicit z [B,HW] or nullptr -> Philox keyed by t
+    uint64_t seed, slice0;
+    int B, HW;
+    int finalize;                     // 1: also map to [0,1] (cond_DDPM.py:513)
+};
+void launch_ddim_step(const DdimArgs& a, hipStream_t stream);
 void launch_noise_fill(float* out, uint64_t seed, uint32_t stream_id, int t, uint64_t slice0, int B, int HW,
                        hipStream_t stream);
 void launch_q_sample(const float* x01, const float* noise, const int* t_dev, const float* sa, const float* s1ma,

@@ -348,6 +348,53 @@ void launch_step(const StepArgs& a, hipStream_t stream) {
     hipLaunchKernelGGL(step_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, a);
 }
 
+// ------------------------------------------------------------------------------------------------
+// DDIM update (src/models/modules/cond_DDPM.py:487-513; model_predictions :400-420 with clip_x_start = False, so the
+// noise estimate uses the unclipped x0; the clamp of :496 comes after). Products and sums rounded separately, in the
+// order of the reference's tensor expression.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ddim_step_kernel(const DdimArgs a) {
+    const int nq = a.HW >> 2;
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (long long)a.B * nq) return;
+    const int q = (int)(e % nq);
+    const int b = (int)(e / nq);
+    const int t = a.t_dev[b];
+    const size_t off = (size_t)b * a.HW + 4 * q;
+    const float4 x4 = *reinterpret_cast<const float4*>(a.x + off);
+    const float4 mo4 = *reinterpret_cast<const float4*>(a.model_out + off);
+    float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.add_noise) {
+        if (a.noise) z4 = *reinterpret_cast<const float4*>(a.noise + off);
+        else z4 = normal4((uint32_t)q, (uint32_t)t, (uint32_t)(a.slice0 + b), 0x1002u, a.seed);
+    }
+    const float sr = a.sqrt_recip[t], srm1 = a.sqrt_recipm1[t];
+    const float xs[4] = {x4.x, x4.y, x4.z, x4.w}, ms[4] = {mo4.x, mo4.y, mo4.z, mo4.w}, zs[4] = {z4.x, z4.y, z4.z, z4.w};
+    float rs[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float x0, eps;
+        if (a.objective == 0) {      // pred_x0
+            x0 = ms[i];
+            eps = __fdiv_rn(__fsub_rn(__fmul_rn(sr, xs[i]), x0), srm1);
+        } else {                     // pred_noise
+            eps = ms[i];
+            x0 = __fsub_rn(__fmul_rn(sr, xs[i]), __fmul_rn(srm1, eps));
+        }
+        x0 = fminf(fmaxf(x0, -1.f), 1.f);
+        float r = __fadd_rn(__fmul_rn(x0, a.coef_x0), __fmul_rn(a.coef_eps, eps));
+        r = __fadd_rn(r, __fmul_rn(a.sigma, zs[i]));
+        if (a.finalize) r = (r + 1.f) * 0.5f;
+        rs[i] = r;
+    }
+    *reinterpret_cast<float4*>(a.x + off) = make_float4(rs[0], rs[1], rs[2], rs[3]);
+}
+
+void launch_ddim_step(const DdimArgs& a, hipStream_t stream) {
+    const long long total = (long long)a.B * (a.HW / 4);
+    hipLaunchKernelGGL(ddim_step_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, a);
+}
+
 // q_sample fused with normalize_to_neg_one_to_one (cond_DDPM.py:548-554, :75, :653)
 __global__ __launch_bounds__(256) void q_sample_kernel(const float* __restrict__ x01, const float* __restrict__ noise,
                                                        const int* __restrict__ t_dev, const float* __restrict__ sa,

@@ -187,6 +187,17 @@ class CddpmEngine:
                                          _stream_ptr(self.device)), "cddpm_p_sample")
         return x
 
+    def ddim_step(self, x: torch.Tensor, t: int, coef_x0: float, coef_eps: float, sigma: float, *, add_noise: bool,
+                  finalize: bool = False, z: Optional[torch.Tensor] = None, seed: int = 0, slice0: int = 0) -> torch.Tensor:
+        """one DDIM update in place on a device tensor (context from the last prepare_cond); see cddpm_ddim_step"""
+        x = _check_dev(x, "x", self.device)
+        B, _c, H, W = x.shape
+        zp = _check_dev(z, "z", self.device).data_ptr() if z is not None else None
+        self._ck(self.lib.cddpm_ddim_step(self._h, x.data_ptr(), zp, seed, slice0, int(t), float(coef_x0), float(coef_eps),
+                                          float(sigma), int(bool(add_noise)), int(bool(finalize)), B, H, W,
+                                          _stream_ptr(self.device)), "cddpm_ddim_step")
+        return x
+
     def p_sample_(self, x: torch.Tensor, t: int, *, seed: int = 0, slice0: int = 0) -> torch.Tensor:
         """in-place reverse step on a device tensor, context from the last prepare_cond (bench loop)"""
         B, _c, H, W = x.shape

@@ -108,6 +108,17 @@ int cddpm_reverse(cddpm_handle h, float* img_inout_dev, const float* noise_dev, 
 int cddpm_p_sample(cddpm_handle h, float* img_inout_dev, const float* z_dev, uint64_t seed, uint64_t slice0,
                    int t, int B, int H, int W, void* stream);
 
+/* Replaces one iteration of GaussianDiffusion.ddim_sample's loop (src/models/modules/cond_DDPM.py:487-511): UNet at
+ * t = `time`, eps from the UNCLIPPED x0 (model_predictions :400-420, clip_x_start = False), x0 clamped to [-1,1] (:496),
+ * img <- x0 * coef_x0 + coef_eps * eps + sigma * z. The caller supplies what the reference computes from
+ * alphas_cumprod_prev[time], alphas_cumprod_prev[time_next] in fp32 (:489-499): coef_x0 = sqrt(alpha_next),
+ * sigma = eta sqrt((1 - alpha/alpha_next)(1 - alpha_next)/(1 - alpha)), coef_eps = sqrt(1 - alpha_next - sigma^2);
+ * add_noise = (time_next > 0); z_dev = the step's N(0,1) draw or NULL for the device Philox keyed by t;
+ * finalize != 0 on the last pair also maps the result to [0,1] (:513). */
+int cddpm_ddim_step(cddpm_handle h, float* img_inout_dev, const float* z_dev, uint64_t seed, uint64_t slice0,
+                    int t, float coef_x0, float coef_eps, float sigma, int add_noise, int finalize,
+                    int B, int H, int W, void* stream);
+
 /* Replaces torch.randn(shape) / torch.randn_like (src/models/modules/cond_DDPM.py:454, :440) with the
  * counter RNG: out_dev [B,1,H,W] ~ N(0,1); stream_id 0x1001 = x_T, 0x1002 = z_t. */
 int cddpm_noise_fill(cddpm_handle h, float* out_dev, uint64_t seed, uint32_t stream_id, int t,

@@ -264,6 +264,51 @@ def p_sample_loop(x_T: Tensor, cond: Optional[Tensor], sd, buf, noises, start_t:
     return (img + 1) * 0.5
 
 
+def ddim_time_pairs(num_timesteps: int, sampling_timesteps: int, start_t: int = 0):
+    """(time, time_next) pairs of ddim_sample (cond_DDPM.py:468-474)."""
+    total = num_timesteps if start_t == 0 else start_t
+    times = torch.linspace(0.0, total, steps=sampling_timesteps + 2)[:-1]
+    times = list(reversed(times.int().tolist()))
+    return list(zip(times[:-1], times[1:]))
+
+
+def ddim_sample(x_T: Tensor, cond: Optional[Tensor], sd, buf, noises, sampling_timesteps: int, eta: float = 1.0,
+                start_t: int = 0, x_start: Optional[Tensor] = None, objective: str = "pred_x0", **unet_kw) -> Tensor:
+    """ddim_sample, Gaussian branch (cond_DDPM.py:466-515). x_T is the N(0,1) draw that is USED (the reference draws one
+    more before it and throws it away, :479/:484; with start_t != 0 the used draw is q_sample's noise, :482).
+    Per pair: alpha = alphas_cumprod_prev[time], alpha_next = alphas_cumprod_prev[time_next] (:489-490);
+    model_predictions with clip_x_start = False (:494, :400-420): eps from the UNCLIPPED x0, then x0.clamp_ (:496);
+    sigma = eta sqrt((1 - alpha/alpha_next)(1 - alpha_next)/(1 - alpha)), c = sqrt(1 - alpha_next - sigma^2) (:498-499);
+    img = x0 sqrt(alpha_next) + c eps + sigma z, z = randn_like if time_next > 0 else 0 (:501-511); (img + 1)/2 (:513).
+    `noises(time)` returns z for the pair whose current step is `time`."""
+    T = buf["betas"].shape[0]
+    dt = x_T.dtype
+    acp = buf["alphas_cumprod_prev"]
+    img = x_T
+    if start_t != 0:
+        tt = torch.tensor([start_t])
+        img = q_sample(x_start, tt, x_T, buf)[:, 0].unsqueeze(1)
+    b = x_T.shape[0]
+    with torch.no_grad():
+        for time, time_next in ddim_time_pairs(T, sampling_timesteps, start_t):
+            alpha, alpha_next = acp[time], acp[time_next]
+            out = unet_forward(img, torch.full((b,), time, dtype=torch.long), cond, sd, **unet_kw)
+            if objective == "pred_x0":
+                pred_noise = (buf["sqrt_recip_alphas_cumprod"][time] * img - out) / buf["sqrt_recipm1_alphas_cumprod"][time]
+                x0 = out
+            elif objective == "pred_noise":
+                pred_noise = out
+                x0 = buf["sqrt_recip_alphas_cumprod"][time] * img - buf["sqrt_recipm1_alphas_cumprod"][time] * out
+            else:
+                raise ValueError(f"unknown objective {objective}")
+            x0 = x0.clamp(-1.0, 1.0)
+            sigma = eta * ((1 - alpha / alpha_next) * (1 - alpha_next) / (1 - alpha)).sqrt()
+            c = ((1 - alpha_next) - sigma ** 2).sqrt()
+            z = noises(time).to(dt) if time_next > 0 else 0.0
+            img = x0 * alpha_next.sqrt() + c * pred_noise + sigma * z
+    return (img + 1) * 0.5
+
+
 def p_losses_recon(x_start01: Tensor, t: Tensor, cond: Optional[Tensor], noise: Tensor, sd, buf,
                    objective: str = "pred_x0", loss_type: str = "l1", **unet_kw):
     """GaussianDiffusion.forward -> p_losses, no box/mask (cond_DDPM.py:565-655): the single-step

@@ -57,6 +57,37 @@ def test_p_sample_loop_mirror(diffusion, synth):
     assert c.shape == (B, 1, H, W)
 
 
+@pytest.mark.parametrize("name,S,eta,start_t", [("ddim_B2_32x32_T1000_S10_eta1", 10, 1.0, 0),
+                                                ("ddim_B2_32x32_T1000_S10_eta0", 10, 0.0, 0),
+                                                ("ddim_B2_32x32_T1000_S6_eta1_start300", 6, 1.0, 300)])
+def test_ddim_sample_mirror(diffusion, synth, oracle, name, S, eta, start_t):
+    """GaussianDiffusion.ddim_sample (cond_DDPM.py:466-515) on the device vs the reference's golden output"""
+    B, H, W = 2, 32, 32
+    d = diffusion
+    old = (d.sampling_timesteps, d.is_ddim_sampling, d.ddim_sampling_eta)
+    d.sampling_timesteps, d.is_ddim_sampling, d.ddim_sampling_eta = S, True, eta
+    try:
+        assert d.ddim_time_pairs(start_t) == oracle.ddim_time_pairs(1000, S, start_t)
+        x = torch.from_numpy(synth.noise_xT(2, 0, B, H, W)).cuda()
+        cond = torch.from_numpy(synth.synth_cond(1, 0, B)).cuda()
+        x_start = (torch.from_numpy(synth.synth_slices(4, 0, B, H, W)) * 2 - 1).cuda() if start_t else None
+        zs = {t: torch.from_numpy(synth.noise_z(3, t, 0, B, H, W)).cuda() for t, nxt in d.ddim_time_pairs(start_t) if nxt > 0}
+        out = d.ddim_sample((B, 1, H, W), cond=cond, x_start=x_start, start_t=start_t, x_T=x, z_noise=zs)
+        ref = golden(name)["out"]
+        err = np.abs(out.cpu().numpy() - ref).max()
+        print(name, f"max|delta| vs reference golden: {err:.3e}")
+        assert err < TOL, err
+        if start_t == 0:
+            # reference call shape through sample(): draws come from the counter RNG, reproducible through torch.manual_seed
+            torch.manual_seed(7)
+            a = d.sample(batch_size=B, cond=cond)
+            torch.manual_seed(7)
+            b = d.sample(batch_size=B, cond=cond)
+            assert torch.equal(a, b) and a.shape == (B, 1, H, W) and float(a.min()) >= 0 and float(a.max()) <= 1
+    finally:
+        d.sampling_timesteps, d.is_ddim_sampling, d.ddim_sampling_eta = old
+
+
 def test_single_step_forward_mirror(diffusion, synth):
     g = golden("p_losses_B2_32x32_t499")
     B, H, W = 2, 32, 32

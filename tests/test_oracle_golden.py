@@ -91,6 +91,32 @@ def test_reverse_loop(oracle, synth, sd_torch, name, T, start_t, B, H, W, slice0
     assert ref.min() >= 0 and ref.max() <= 1 and ref.std() > 0.01
 
 
+DDIM = {"ddim_B2_32x32_T1000_S10_eta1": (32, 32, 2, 1000, 10, 1.0, 0),
+        "ddim_B2_32x32_T1000_S10_eta0": (32, 32, 2, 1000, 10, 0.0, 0),
+        "ddim_B2_32x32_T1000_S6_eta1_start300": (32, 32, 2, 1000, 6, 1.0, 300),
+        "ddim_B1_64x64_T50_S7_eta05": (64, 64, 1, 50, 7, 0.5, 0)}
+
+
+@pytest.mark.parametrize("name", list(DDIM))
+def test_ddim_sample(oracle, synth, sd_torch, name):
+    """ddim_sample restatement vs the reference's own output (oracle/make_golden_ddim.py); the manifest records
+    max|oracle - reference| = 0.0 for these cases at generation time."""
+    H, W, B, T, S, eta, start_t = DDIM[name]
+    x, cond = _inputs(synth, B, H, W, 0)
+    x_start = torch.from_numpy(synth.synth_slices(4, 0, B, H, W)) * 2 - 1 if start_t else None
+    out = oracle.ddim_sample(x, cond, sd_torch, oracle.schedule_buffers(T),
+                             lambda t: torch.from_numpy(synth.noise_z(3, t, 0, B, H, W)), S, eta, start_t, x_start).numpy()
+    ref = golden(name)["out"]
+    assert np.abs(out - ref).max() <= TOL
+    assert ref.min() >= 0 and ref.max() <= 1 and ref.std() > 0.01
+    pairs = oracle.ddim_time_pairs(T, S, start_t)
+    assert len(pairs) == S and pairs[-1][1] == 0 and all(a > b for a, b in pairs)
+    import json, os
+    from conftest import GOLD
+    man = json.load(open(os.path.join(GOLD, "MANIFEST.json")))["cases"][name]
+    assert man["oracle_vs_reference_maxabs"] == 0.0 and [tuple(p) for p in man["time_pairs"]] == pairs
+
+
 def test_single_step_reconstruction(oracle, synth, sd_torch):
     g = golden("p_losses_B2_32x32_t499")
     B, H, W = 2, 32, 32
