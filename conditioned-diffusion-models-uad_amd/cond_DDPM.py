@@ -223,6 +223,7 @@ class GaussianDiffusion(nn.Module):
                 z = z_noise[time]
             eng.ddim_step(img, time, ca, c, sigma, add_noise=time_next > 0, finalize=(i == len(pairs) - 1),
                           z=z.to(dev).float().contiguous() if z is not None else None, seed=seed, slice0=slice0)
+        eng._check_finite(img, "ddim_sample")
         return img
 
     @torch.no_grad()

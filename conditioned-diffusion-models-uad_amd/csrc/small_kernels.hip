@@ -296,6 +296,9 @@ void launch_noise_fill(float* out, uint64_t seed, uint32_t stream_id, int t, uin
 // posterior step: p_sample -> p_mean_variance -> model_predictions -> q_posterior
 // (src/models/modules/cond_DDPM.py:432-444, :422-430, :400-420, :391-398); final map to [0,1] (:463)
 // ------------------------------------------------------------------------------------------------
+// torch.clamp(x, -1, 1): NaN stays NaN (fminf/fmaxf would turn it into -1 and hide an overflow upstream)
+__device__ __forceinline__ float clamp11(float v) { return (v != v) ? v : fminf(fmaxf(v, -1.f), 1.f); }
+
 __global__ __launch_bounds__(256) void step_kernel(const StepArgs a) {
     const int nq = a.HW >> 2;
     const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -316,10 +319,10 @@ __global__ __launch_bounds__(256) void step_kernel(const StepArgs a) {
         x0.z = sr * x.z - srm1 * mo.z;
         x0.w = sr * x.w - srm1 * mo.w;
     }
-    x0.x = fminf(fmaxf(x0.x, -1.f), 1.f);
-    x0.y = fminf(fmaxf(x0.y, -1.f), 1.f);
-    x0.z = fminf(fmaxf(x0.z, -1.f), 1.f);
-    x0.w = fminf(fmaxf(x0.w, -1.f), 1.f);
+    x0.x = clamp11(x0.x);
+    x0.y = clamp11(x0.y);
+    x0.z = clamp11(x0.z);
+    x0.w = clamp11(x0.w);
     const float c1 = a.coef1[t], c2 = a.coef2[t];
     // separate roundings of the two products, as the reference's tensor expression does
     float4 r;
@@ -381,7 +384,7 @@ __global__ __launch_bounds__(256) void ddim_step_kernel(const DdimArgs a) {
             eps = ms[i];
             x0 = __fsub_rn(__fmul_rn(sr, xs[i]), __fmul_rn(srm1, eps));
         }
-        x0 = fminf(fmaxf(x0, -1.f), 1.f);
+        x0 = clamp11(x0);
         float r = __fadd_rn(__fmul_rn(x0, a.coef_x0), __fmul_rn(a.coef_eps, eps));
         r = __fadd_rn(r, __fmul_rn(a.sigma, zs[i]));
         if (a.finalize) r = (r + 1.f) * 0.5f;

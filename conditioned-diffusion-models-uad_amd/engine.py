@@ -173,7 +173,18 @@ class CddpmEngine:
             nptr = noise.data_ptr()
         self._ck(self.lib.cddpm_reverse(self._h, x.data_ptr(), nptr, seed, slice0, t_start, B, H, W,
                                         _stream_ptr(self.device)), "cddpm_reverse")
+        self._check_finite(x, "cddpm_reverse")
         return x
+
+    @staticmethod
+    def _check_finite(x: torch.Tensor, what: str):
+        """A non-finite reconstruction is an error, not a result. The default convolution family carries fp32 products on
+        the fp16 matrix pipe and needs |activation| < 65504; a model that exceeds it overflows to
+        inf/NaN, which the posterior step propagates like torch.clamp does. One reduction + sync per reconstruction."""
+        if not bool(torch.isfinite(x).all().item()):
+            raise FloatingPointError(f"{what}: non-finite values in the result. If the weights are sane, an activation left the "
+                                     "fp16 range of the default convolution family: rerun with CDDPM_CONV=x6 (exact bf16 split, "
+                                     "no range limit) or CDDPM_CONV=f32.")
 
     def p_sample(self, x: torch.Tensor, t: int, cond: Optional[torch.Tensor] = None, *, z: Optional[torch.Tensor] = None,
                  seed: int = 0, slice0: int = 0) -> torch.Tensor:

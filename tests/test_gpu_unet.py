@@ -152,6 +152,13 @@ def test_errors_are_loud(eng1000, synth):
         eng1000.unet_forward(x.cuda()[:, :, :30], 3, cond.cuda())   # H not a multiple of 4
     with pytest.raises(RuntimeError):
         eng1000.unet_forward(x.cuda(), 1000, cond.cuda())           # t out of range
+    # a non-finite value anywhere upstream must surface (torch.clamp semantics in the posterior step), not be clamped away
+    bad = x.clone()
+    bad[1, 0, 5, 7] = float("nan")
+    with pytest.raises(FloatingPointError, match="CDDPM_CONV"):
+        eng1000.reverse(bad.cuda(), cond.cuda(), 2)
+    ok = eng1000.reverse(x.cuda(), cond.cuda(), 2)
+    assert bool(torch.isfinite(ok).all())
 
 
 def test_unet_forward_256_config3(engine_factory, synth, oracle, sd_torch):
