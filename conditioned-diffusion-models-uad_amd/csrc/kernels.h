@@ -47,6 +47,10 @@ void launch_conv_ws(const ConvArgs& a, hipStream_t stream);
 // conv_mfma.hip (CDDPM_CONV=f32). Chosen once per process; it also selects the packed weight format.
 int conv_mode();
 void launch_conv_split(const ConvArgs& a, hipStream_t stream);
+// ping-pong schedule of the fp16-split 3x3 convolution without a skip segment (conv_pp.hip): the two waves of a SIMD
+// alternate between MFMA and staging phases; bit-identical results. Experimental (slower so far): opt-in, CDDPM_CONV_PP=1.
+bool conv_pp_applicable(const ConvArgs& a);
+void launch_conv_pp(const ConvArgs& a, hipStream_t stream);
 // mode 2 only (else 0): power-of-two pre-scale exponent of a weight tensor, max|w| * 2^e in [2^13, 2^14)
 int conv_weight_exp(const float* w, size_t n);
 void pack_conv_weights_split(const float* w /*[Cout][Cin][k][k]*/, int Cout, int Cin, int taps, void* dst, int wexp);

@@ -51,7 +51,11 @@ def child(B, iters):
             row["clock_GHz"] = round(st[40] / st[41] * 0.1, 3)
         if os.environ.get("CDDPM_CONV_WS") == "1" and sum(st[:4]):
             row["ws_cycles"] = {"matrix work": int(st[0]), "matrix barrier": int(st[1]), "staging work": int(st[2]), "staging barrier": int(st[3])}
-        elif os.environ.get("AB_PHASES8") and sum(st[:16]):
+        if sum(st[48:56]):
+            for g in (0, 1):
+                tt = [st[48 + 4 * g + i] for i in range(4)]
+                row["pp_group%d" % g] = {k: round(v / max(1, sum(tt)), 3) for k, v in zip(("compute", "staging", "wait after compute", "wait after staging"), tt)}
+        if os.environ.get("AB_PHASES8") and sum(st[:16]):
             for wv in (0, 1):
                 tt = [st[wv * 8 + i] for i in range(8)]
                 row["wave%d" % (wv * 4)] = {p: round(t / max(1, sum(tt)), 3) for p, t in zip(PHASES8, tt)}
@@ -82,6 +86,8 @@ def main():
                     env["CDDPM_CONV_WS"] = "1"
                 if opt in ("f32", "x6", "h3"):
                     env["CDDPM_CONV"] = opt
+                if opt == "pp":
+                    env["CDDPM_CONV_PP"] = "1"
                 if opt == "zero":
                     env["CDDPM_BENCH_ZERO"] = "1"
                 if opt in ("w4", "w8"):
@@ -101,7 +107,7 @@ def main():
                     line += "  " + json.dumps(runs[0][i]["phase_share"])
                 if "clock_GHz" in runs[0][i]:
                     line += f"  clock {runs[0][i]['clock_GHz']} GHz"
-                for wk in ("wave0", "wave4"):
+                for wk in ("wave0", "wave4", "pp_group0", "pp_group1"):
                     if wk in runs[0][i]:
                         line += "\n        " + wk + " " + json.dumps(runs[0][i][wk])
                 if "ws_cycles" in runs[0][i]:
