@@ -216,6 +216,11 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(const ConvArgs a) {
     f16x8 pa[2][2], pb[2][2];
 #ifdef CDDPM_STAMPS
     unsigned long long st_[4] = {0, 0, 0, 0};      // compute phase work, staging phase work, barrier wait after compute / after staging
+    unsigned long long fine_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // segments inside the phases (group 0 only)
+    unsigned long long tl_ = 0;
+#define PST(i) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long n_ = __builtin_amdgcn_s_memtime(); fine_[i] += n_ - tl_; tl_ = n_; }
+#else
+#define PST(i)
 #endif
     if (grp == 0) load_frags(0, 0, pa, pb);        // group 0 computes first
     v4f entA = v4f{0.f, 0.f, 0.f, 0.f}, entB = entA;   // patch entries in flight: even / odd taps
@@ -231,6 +236,7 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(const ConvArgs a) {
 #ifdef CDDPM_STAMPS
         const unsigned long long tp0_ = __builtin_amdgcn_s_memtime();
         const bool was_compute_ = ((phi & 1) == grp);
+        tl_ = tp0_;
 #endif
         const bool more = chunk + 1 < nch;
         v4f& ent_other = PARITY ? entA : entB;
@@ -239,7 +245,9 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(const ConvArgs a) {
             // (k-step 1 reuses the fragment registers: its reads are issued behind the 12 MFMAs of k-step 0, which cover
             // the LDS latency -- the other group is not reading fragments now -- and 32 VGPRs stay free.)
             products(pa, pb, (tap % 3) == 0);
+            PST(0)
             load_frags(s, 1, pa, pb);
+            PST(1)
             // One entry of the NEXT chunk's patch is normalised / activated / split / written here, in the issue slots the
             // MFMAs leave free (an MFMA holds the vector issue port 8 of its 32 cycles): the entry this wave requested three
             // phases ago -- for group 0 that was stage s - 2 (same parity set), for group 1 stage s - 1 (the other set),
@@ -253,7 +261,9 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(const ConvArgs a) {
                     store_entry(k, p_st, grp ? ent_other : ent, cm, ca, cd, lds + ((chunk + 1) & 1) * (NPIX * SP));
                 }
             }
+            PST(2)
             products(pa, pb, false);
+            PST(3)
         } else {
             // ============ staging phase
             // the stage this wave computed last (group 1 runs one phase behind group 0) and the one it computes next
@@ -266,18 +276,22 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(const ConvArgs a) {
 #pragma unroll
                     for (int j = 0; j < 2; ++j) tot[i][j] += acc[i][j];
             }
+            PST(4)
             // weight slab of stage s + 2: this thread's pieces into the slot stage s - 1 used (both groups are done with it)
             if (s + 2 < N) {
 #pragma unroll
                 for (int i = 0; i < WK; ++i) ldsW[((s + 2) % NWS) * WSLOTS + tid + THREADS * i] = wreg[i];
             }
+            PST(5)
             // ---- requests: next slab pieces, patch entry `tap` of the next chunk (stored from a compute phase, see above)
 #pragma unroll
             for (int i = 0; i < WK; ++i) wreg[i] = slab_ptr(s + 3)[tid + THREADS * i];
             if (do_ld) ent = load_entry(chunk + 1, p_ld);
+            PST(6)
             // k-step 0 fragments of the stage this wave computes next (LDS only; nobody waits for them before the barrier)
             const int s_next = s_done + 1;
             if (s_next < N) load_frags(s_next, 0, pa, pb);
+            PST(7)
         }
 #ifdef CDDPM_STAMPS
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -306,6 +320,8 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(const ConvArgs a) {
 #ifdef CDDPM_STAMPS
     if (a.stamps && lane == 0 && (wave & 3) == 0)
         for (int i = 0; i < 4; ++i) atomicAdd(&a.stamps[48 + grp * 4 + i], st_[i]);
+    if (a.stamps && lane == 0 && wave == 0)
+        for (int i = 0; i < 8; ++i) atomicAdd(&a.stamps[i], fine_[i]);
 #endif
     // group 1 computed the last stage in the last phase: its fold is still due (group 0 folded in that phase)
     if (grp == 1) {

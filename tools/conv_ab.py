@@ -51,6 +51,10 @@ def child(B, iters):
             row["clock_GHz"] = round(st[40] / st[41] * 0.1, 3)
         if os.environ.get("CDDPM_CONV_WS") == "1" and sum(st[:4]):
             row["ws_cycles"] = {"matrix work": int(st[0]), "matrix barrier": int(st[1]), "staging work": int(st[2]), "staging barrier": int(st[3])}
+        if sum(st[48:56]) and sum(st[:8]):
+            tt = [st[i] for i in range(8)]
+            names = ("c:mfma k0", "c:frag reads k1", "c:patch entry", "c:mfma k1", "s:fold", "s:weight write", "s:requests", "s:frag prefetch")
+            row["pp_fine"] = {k: round(v / max(1, sum(tt)), 3) for k, v in zip(names, tt)}
         if sum(st[48:56]):
             for g in (0, 1):
                 tt = [st[48 + 4 * g + i] for i in range(4)]
@@ -107,7 +111,7 @@ def main():
                     line += "  " + json.dumps(runs[0][i]["phase_share"])
                 if "clock_GHz" in runs[0][i]:
                     line += f"  clock {runs[0][i]['clock_GHz']} GHz"
-                for wk in ("wave0", "wave4", "pp_group0", "pp_group1"):
+                for wk in ("wave0", "wave4", "pp_group0", "pp_group1", "pp_fine"):
                     if wk in runs[0][i]:
                         line += "\n        " + wk + " " + json.dumps(runs[0][i][wk])
                 if "ws_cycles" in runs[0][i]:
