@@ -160,7 +160,8 @@ def main():
         "value": value, "unit": "slices/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": s_per_step * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"configs[1]: reference UNet (43.87M params, fp32), {B}x1x{S}x{S} slices per GPU, "
+        "config": {"workload": ("configs[1]" if (S == 128 and B == 64) else ("configs[2] geometry (256x256)" if S == 256 else "non-headline geometry"))
+                               + f": reference UNet (43.87M params, fp32), {B}x1x{S}x{S} slices per GPU, "
                                f"T={T_TOTAL}, p_sample steps t={T_TOTAL - 1 - args.warmup}..{t + 1}; value = n_gpus*B/(T*s_per_step)",
                    "arithmetic": {"h3": "fp32 in, fp32 out, fp32 accumulation; convolution products formed from two-term fp16 splits of both "
                                         "operands (|x - hi - mid| <= 2^-23 |x|, rms 0.73 x 2^-24; weights pre-scaled by a power of two) on the fp16 MFMA, 3 of 4 "
