@@ -9,9 +9,8 @@ Added, behind a cfg switch that is absent (= reference behaviour) by default:
                                      (GaussianDiffusion.p_sample_loop) instead of the single-step x0 estimate
     cfg.reverse_start_t: int     ->  start_t of that loop (0 = all `timesteps` steps)
 
-Out of scope here ('next' rows): the timm ResNet-50 context encoder (f2) -- built through
-timm when it is importable, otherwise an `encoder=` module must be supplied; simplex noise (f3); training and the
-scipy post-processing of utils_eval (f4). pytorch_lightning / omegaconf are used when installed and replaced by
+The context encoder is this package's native ResNet-50 (DDPM_encoder.py) unless an
+`encoder=` module is supplied. Out of scope here: training and the scipy post-processing of utils_eval (f4). pytorch_lightning / omegaconf are used when installed and replaced by
 nn.Module / a plain attribute dict when not.
 """
 from __future__ import annotations
@@ -48,16 +47,12 @@ def _cfg_get(cfg, key, default=None):
 
 
 def build_encoder(cfg):
-    """get_encoder (reference src/models/modules/DDPM_encoder.py:6-29): timm resnet50, in_chans=1,
-    num_classes=cond_dim. Parity of this module is unpinned offline (timm 0.6.7 is not in the image)."""
-    try:
-        import timm  # type: ignore
-    except Exception as e:
-        raise ImportError("the Spark context encoder needs timm (resnet50, in_chans=1, num_classes=cond_dim); "
-                          "timm is not importable here -- pass DDPM_2D(cfg, encoder=<module>) instead") from e
-    dim = int(_cfg_get(cfg, "cond_dim", 128))
-    enc = timm.create_model(_cfg_get(cfg, "version", "resnet50"), pretrained=False, in_chans=1, num_classes=dim)
-    return enc, dim
+    """get_encoder (reference src/models/modules/DDPM_encoder.py:6-29, called at DDPM_2D.py:32): the native MI355X
+    encoder of this package (DDPM_encoder.py / csrc/encoder.hip: timm's resnet50 layout with in_chans=1,
+    num_classes=cond_dim, plain or wrapped as SparK_2D_encoder as the cfg's `backbone` says). Its parity is unpinned
+    offline: timm 0.6.7 is not in the image (oracle/encoder_oracle.py restates the published architecture)."""
+    from .DDPM_encoder import get_encoder
+    return get_encoder(cfg)
 
 
 class DDPM_2D(_Base):

@@ -66,6 +66,12 @@ SYMBOLS = {
                                  C.POINTER(_u64)]),
     "cddpm_op_gn_coef": (_i, [_vp, _fp, _i, _fp, _i, _fp, _fp, _fp, _fp, _i, _i, _vp]),
     "cddpm_op_attention": (_i, [_vp, _fp, _fp, _i, _i, _i, _vp]),
+    "cddpm_encoder_create": (_i, [C.POINTER(_vp), _i, _i, _i, _i, _i]),
+    "cddpm_encoder_destroy": (None, [_vp]),
+    "cddpm_encoder_last_error": (C.c_char_p, [_vp]),
+    "cddpm_encoder_num_weights": (_i, []),
+    "cddpm_encoder_load_weights": (_i, [_vp, C.POINTER(C.c_char_p), C.POINTER(_fp), C.POINTER(_i64), _i]),
+    "cddpm_encoder_forward": (_i, [_vp, _fp, _fp, _i, _i, _i, _vp]),
     "cddpm_packed_conv_bytes": (_sz, [_i, _i, _i]),
     "cddpm_pack_conv_weights": (_i, [_fp, _i, _i, _i, _vp, C.POINTER(_i)]),
 }

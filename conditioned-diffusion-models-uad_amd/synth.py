@@ -228,3 +228,58 @@ def synth_state_dict(seed: int = 0, **unet_kwargs):
             v = (np.float32(2.0) * u - np.float32(1.0)) * bound
         sd[name] = np.ascontiguousarray(v.astype(np.float32).reshape(shape))
     return sd
+
+
+# ----------------------------------------------------------------------------------------------
+# synthetic context-encoder weights (timm resnet50, in_chans=1) with timm's state_dict names and shapes
+# ----------------------------------------------------------------------------------------------
+STREAM_ENC_WEIGHT = 0x3000   # + tensor ordinal
+ENCODER_STAGES = ((64, 3), (128, 4), (256, 6), (512, 3))
+
+
+def encoder_param_shapes(num_classes: int = 128):
+    """name -> shape of timm's ResNet-50 (v1.5) with a 1-channel stem, in state_dict order (num_batches_tracked omitted)"""
+    shapes = {"conv1.weight": (64, 1, 7, 7)}
+
+    def bn(p, c):
+        for k in ("weight", "bias", "running_mean", "running_var"):
+            shapes[f"{p}.{k}"] = (c,)
+    bn("bn1", 64)
+    inplanes = 64
+    for s, (planes, nblocks) in enumerate(ENCODER_STAGES):
+        for i in range(nblocks):
+            p = f"layer{s + 1}.{i}"
+            shapes[p + ".conv1.weight"] = (planes, inplanes, 1, 1); bn(p + ".bn1", planes)
+            shapes[p + ".conv2.weight"] = (planes, planes, 3, 3); bn(p + ".bn2", planes)
+            shapes[p + ".conv3.weight"] = (planes * 4, planes, 1, 1); bn(p + ".bn3", planes * 4)
+            if i == 0:
+                shapes[p + ".downsample.0.weight"] = (planes * 4, inplanes, 1, 1); bn(p + ".downsample.1", planes * 4)
+            inplanes = planes * 4
+    shapes["fc.weight"] = (num_classes, 2048)
+    shapes["fc.bias"] = (num_classes,)
+    return shapes
+
+
+def synth_encoder_state_dict(seed: int = 0, num_classes: int = 128):
+    """Synthetic encoder weights (numpy float32): conv / fc ~ U(+-sqrt(3 / fan_in)) (unit gain, keeps activations O(1)
+    through 50 layers), BatchNorm gamma = 1 + 0.1 n, beta = 0.1 n, running_mean = 0.1 n, running_var = 1 + 0.2 u."""
+    shapes = encoder_param_shapes(num_classes)
+    sd = {}
+    for ordinal, (name, shape) in enumerate(shapes.items()):
+        n = int(np.prod(shape))
+        nq = (n + 3) // 4
+        stream = STREAM_ENC_WEIGHT + ordinal
+        leaf = name.rsplit(".", 1)[1]
+        if len(shape) == 1 and not name.startswith("fc."):
+            if leaf == "running_var":
+                v = np.float32(1.0) + np.float32(0.2) * uniform_quads(nq, 0, 0, stream, seed)[:n]
+            else:
+                z = normal_quads(nq, 0, 0, stream, seed)[:n]
+                v = (np.float32(1.0) + np.float32(0.1) * z) if leaf == "weight" else np.float32(0.1) * z
+        else:
+            wshape = shapes[name[: name.rfind(".")] + ".weight"]
+            fan_in = int(np.prod(wshape[1:]))
+            bound = np.float32(math.sqrt(3.0 / fan_in))
+            v = (np.float32(2.0) * uniform_quads(nq, 0, 0, stream, seed)[:n] - np.float32(1.0)) * bound
+        sd[name] = np.ascontiguousarray(v.astype(np.float32).reshape(shape))
+    return sd

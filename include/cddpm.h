@@ -203,6 +203,23 @@ int cddpm_pack_conv_weights(const float* w_host, int Cout, int Cin, int taps, vo
  * out [B,N,C] = softmax(q k^T / sqrt(head_channels)) v  (QKVAttention, OpenAI_Unet.py:457-476). */
 int cddpm_op_attention(cddpm_handle h, const float* qkv_dev, float* out_dev, int B, int N, int C, void* stream);
 
+/* ---- context encoder ---------------------------------------------------------------
+ * Replaces the module get_encoder builds (src/models/modules/DDPM_encoder.py:6-29): timm resnet50(in_chans=1,
+ * num_classes=cond_dim) in eval mode, called once per slice batch by DDPM_2D.forward (src/models/DDPM_2D.py:98-104).
+ * PARITY UNPINNED: timm is not installed in the build image; the network follows timm's published ResNet-50 v1.5 and
+ * its state_dict names and is checked against a torch restatement of that description (oracle/encoder_oracle.py).
+ * load_weights takes host pointers under timm's key names (conv1.weight, bn1.{weight,bias,running_mean,running_var},
+ * layer{1..4}.{i}.{conv1,bn1,conv2,bn2,conv3,bn3,downsample.0,downsample.1}.*, fc.{weight,bias}); BatchNorm is folded.
+ * forward: x_dev [B,1,H,W] fp32 in [0,1] (H, W >= 32) -> out_dev [B, num_classes] on the caller's stream. */
+typedef struct cddpm_encoder_ctx* cddpm_encoder_handle;
+int cddpm_encoder_create(cddpm_encoder_handle* out, int num_classes, int max_batch, int max_h, int max_w, int device);
+void cddpm_encoder_destroy(cddpm_encoder_handle h);
+const char* cddpm_encoder_last_error(cddpm_encoder_handle h);
+int cddpm_encoder_num_weights(void);
+int cddpm_encoder_load_weights(cddpm_encoder_handle h, const char* const* names, const float* const* host_ptrs,
+                               const int64_t* numels, int n);
+int cddpm_encoder_forward(cddpm_encoder_handle h, const float* x_dev, float* out_dev, int B, int H, int W, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

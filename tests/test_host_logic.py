@@ -113,8 +113,43 @@ def test_ddpm2d_mirror_builds_from_experiment_cfg():
     keys = list(mod.state_dict().keys())
     assert any(k.startswith("diffusion.model.output_blocks.11.0.") for k in keys) and "diffusion.betas" in keys
     assert mod(torch.zeros(3, 1, 96, 96)).shape == (3, 128)
-    with pytest.raises(ImportError):
-        M.DDPM_2D(dict(cfg))          # timm absent: the encoder must be supplied, nothing is faked
+    # without `encoder=` the package's native encoder is built: the experiment's backbone is the SparK wrapper around a
+    # resnet50 whose weights sit under encoder.encoder.* in the reference's checkpoints (Spark_2D.py:268-290)
+    full = M.DDPM_2D(dict(cfg, backbone="Spark_Encoder_2D", version="resnet50"))
+    ek = [k for k in full.state_dict() if k.startswith("encoder.")]
+    assert "encoder.encoder.conv1.weight" in ek and "encoder.encoder.layer4.2.bn3.running_var" in ek and "encoder.encoder.fc.bias" in ek
+    assert full.state_dict()["encoder.encoder.fc.weight"].shape == (128, 2048)
+    assert full.state_dict()["encoder.encoder.conv1.weight"].shape == (64, 1, 7, 7)
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError, match="MI355X|CUDA"):
+            full(torch.zeros(1, 1, 96, 96))           # no CPU fallback
+    with pytest.raises(NotImplementedError):
+        M.DDPM_2D(dict(cfg, backbone="resnet101"))
+
+
+def test_encoder_mirror_inventory_and_oracle_shapes(synth):
+    """timm resnet50 (in_chans=1) inventory: 161 weight tensors + 53 x (running_mean, running_var, num_batches_tracked);
+    the oracle restatement runs on the synthetic weights and is sensitive to every stage."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import encoder_oracle as EO
+    E = load_pkg("DDPM_encoder")
+    shapes = synth.encoder_param_shapes(128)
+    enc = E.ResNet50Encoder(num_classes=128)
+    sd = enc.state_dict()
+    assert set(k for k in sd if not k.endswith("num_batches_tracked")) == set(shapes)
+    assert sum(k.endswith("num_batches_tracked") for k in sd) == 53
+    # torchvision/timm resnet50: 25,557,032 parameters; 1-channel stem (-6,272) and a 128-way fc (-1,786,728)
+    assert sum(int(np.prod(s)) for n, s in shapes.items() if "running" not in n) == 25_557_032 - 6_272 - 1_786_728
+    w = synth.synth_encoder_state_dict(0, 128)
+    enc.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()}, strict=False)
+    sdt = {k: torch.from_numpy(v) for k, v in w.items()}
+    x = torch.from_numpy(synth.synth_slices(4, 0, 2, 64, 64))
+    y = EO.resnet50_forward(x, sdt)
+    assert y.shape == (2, 128) and torch.isfinite(y).all() and 0.05 < float(y.std()) < 50
+    sdt2 = dict(sdt)
+    sdt2["layer3.4.conv2.weight"] = sdt["layer3.4.conv2.weight"] * 1.01
+    assert float((EO.resnet50_forward(x, sdt2) - y).abs().max()) > 1e-6
 
 
 def test_library_exports_every_declared_symbol():
