@@ -88,7 +88,10 @@ __device__ __forceinline__ void split_x4(const v4f v, typename SplitT<NS>::v4 (&
     }
 }
 
-template <int TAPS, int ROWS, int NS>
+// M16X: the fp16 form on v_mfma_f32_16x16x32_f16 (one MFMA spans a tap's whole 32-channel chunk; 16 tiles of 16 x 16 per
+// wave) instead of 32x32x16: +3-5 % on layers with many channel chunks, -2-3 % on 128 -> 128, so the launcher picks it
+// per layer; half as many accumulate roundings per product.
+template <int TAPS, int ROWS, int NS, bool M16X = false>
 __global__ __launch_bounds__(64 * ROWS) void conv_split_kernel(const ConvArgs a) {
     typedef typename SplitT<NS>::v8 frag;
     constexpr int SP = 4 * NS;                          // 16-B slots per pixel / per cout row
@@ -236,13 +239,36 @@ __global__ __launch_bounds__(64 * ROWS) void conv_split_kernel(const ConvArgs a)
         }
     };
 
-    f32x16 acc[2][2], tot[2][2];
+    constexpr bool M16 = M16X && (NS == 2);
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    f32x16 acc[2][2], tot[2][2];            // 32 x 32 form: [pixel row][cout 32-tile]
+    f32x4 acc16[4][4], tot16[4][4];         // 16 x 16 form: [pixel 16-group][cout 16-group]  (only one of the two sets is live)
+    if constexpr (M16) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < 4; ++j) { acc16[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; tot16[i][j] = acc16[i][j]; }
+    } else {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; tot[i][j][r] = 0.f; }
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; tot[i][j][r] = 0.f; }
+    }
+    auto fold_acc = [&]() {
+        if constexpr (M16) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) tot16[i][j] += acc16[i][j];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) tot[i][j] += acc[i][j];
+        }
+    };
 
     // B operand (weights) LDS offsets: row j = cout within the 128 block
     int brow[2];
@@ -254,6 +280,46 @@ __global__ __launch_bounds__(64 * ROWS) void conv_split_kernel(const ConvArgs a)
         const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         const int ky = (TAPS == 9) ? (tap / 3) : (UP2 ? (tap >> 1) : 0);
         const int kx = (TAPS == 9) ? (tap - 3 * ky) : (UP2 ? (tap & 1) : 0);
+        if constexpr (M16) {
+            // lane (r = lane & 15, g = lane >> 4) holds row r, channels 8 g .. 8 g + 7 of a 16 x 32 operand tile
+            const int r16 = lane & 15, g = lane >> 4;
+            const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+            f16x8 fa[2][4];
+#pragma unroll
+            for (int t16 = 0; t16 < 4; ++t16) {
+                const int arow = (2 * wm + (t16 >> 1) + ky) * PW + (t16 & 1) * 16 + r16 + kx;
+#pragma unroll
+                for (int sp = 0; sp < 2; ++sp) fa[sp][t16] = __builtin_bit_cast(f16x8, ldsA[slot_of(arow, sp, g)]);
+            }
+#pragma unroll
+            for (int nh = 0; nh < 2; ++nh) {            // two cout 16-groups at a time: 12 fragments live instead of 16
+                f16x8 fb[2][2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int browm = 64 * wn + 16 * (2 * nh + j) + r16;
+#pragma unroll
+                    for (int sp = 0; sp < 2; ++sp) fb[sp][j] = __builtin_bit_cast(f16x8, wb[slot_of(browm, sp, g)]);
+                }
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {       // mid*hi, hi*mid, hi*hi
+                    const int sa = (p == 0) ? 1 : 0, sb = (p == 1) ? 1 : 0;
+                    if (p == 0 && first) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+#pragma unroll
+                            for (int j = 0; j < 2; ++j)
+                                acc16[i][2 * nh + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[sa][i], fb[sb][j], zero4, 0, 0, 0);
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+#pragma unroll
+                            for (int j = 0; j < 2; ++j)
+                                acc16[i][2 * nh + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[sa][i], fb[sb][j], acc16[i][2 * nh + j], 0, 0, 0);
+                    }
+                }
+            }
+            return;
+        }
         int arow[2];
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) arow[mt] = (2 * wm + mt + ky) * PW + li + kx;
@@ -334,10 +400,7 @@ __global__ __launch_bounds__(64 * ROWS) void conv_split_kernel(const ConvArgs a)
             buf ^= 1;
             STAMP(3)
             if ((t % FOLD) == FOLD - 1 || last_tap) {
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) tot[i][j] += acc[i][j];
+                fold_acc();
                 STAMP(4)
             }
         }
@@ -415,10 +478,7 @@ __global__ __launch_bounds__(64 * ROWS) void conv_split_kernel(const ConvArgs a)
             buf ^= 1;
             STAMP(3)
             if (((st + 1) * TPS) % FOLD == 0 || last_st) {
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) tot[i][j] += acc[i][j];
+                fold_acc();
                 STAMP(4)
             }
         }
@@ -455,7 +515,8 @@ __global__ __launch_bounds__(64 * ROWS) void conv_split_kernel(const ConvArgs a)
     // ---- epilogue: as conv_mfma.hip -- each wave transposes its 64 x 64 tile through a private 8-KB LDS region so
     //      that every lane moves 16 B; bias, residual and the GroupNorm statistics of the output are applied here.
     {
-        float* tr = reinterpret_cast<float*>(lds) + wave * 2048;      // [64 pixels][32 channels]
+        constexpr int TRS = M16 ? 36 : 32;                            // row stride of the transpose region (36: conflict-free for the 16 x 16 C layout)
+        float* tr = reinterpret_cast<float*>(lds) + wave * (64 * TRS);   // [64 pixels][32 channels]
         const int cq = lane & 7;
         const int prow = lane >> 3;
         const int tilesY4 = (gridH + 3) >> 2;                         // statistics records are per 4-row band (kernels.h)
@@ -463,11 +524,22 @@ __global__ __launch_bounds__(64 * ROWS) void conv_split_kernel(const ConvArgs a)
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
             const int co = cb * 128 + 64 * wn + 32 * nt + 4 * cq;
+            if constexpr (M16) {
+                // C tile layout of the 16 x 16 form: register r of lane l = row 4 (l >> 4) + r (pixel), column l & 15 (cout)
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
+                for (int t16 = 0; t16 < 4; ++t16)
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    tr[(mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * 32 + li] = tot[mt][nt][r];
+                    for (int n2 = 0; n2 < 2; ++n2)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            tr[(16 * t16 + 4 * (lane >> 4) + r) * TRS + 16 * n2 + (lane & 15)] = tot16[t16][2 * nt + n2][r];
+            } else {
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        tr[(mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * 32 + li] = tot[mt][nt][r];
+            }
             __builtin_amdgcn_wave_barrier();
             const v4f bias = a.bias ? *reinterpret_cast<const v4f*>(a.bias + co) : v4f{0.f, 0.f, 0.f, 0.f};
             const float wsc = (NS == 2) ? a.wscale_inv : 1.0f;      // fp16 weights were pre-scaled by a power of two
@@ -484,7 +556,7 @@ __global__ __launch_bounds__(64 * ROWS) void conv_split_kernel(const ConvArgs a)
                     ok[i] = (gy < gridH) && (gx < gridW);
                     const int y = UP2 ? (2 * gy + pa) : gy, x = UP2 ? (2 * gx + pb) : gx;
                     oidx[i] = ((size_t)(b * a.H + y) * a.W + x) * a.Cout + co;
-                    val[i] = *reinterpret_cast<const v4f*>(tr + p * 32 + 4 * cq);
+                    val[i] = *reinterpret_cast<const v4f*>(tr + p * TRS + 4 * cq);
                 }
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
@@ -547,17 +619,22 @@ static void launch_split(const ConvArgs& a, hipStream_t stream) {
     auto need = [&](int npix) {
         const int tps = (NS == 2) ? (a.taps == 9 ? 3 : (a.taps == 4 ? 2 : 1)) : 1;     // taps per weight stage (kernel: TPS)
         const size_t main = (size_t)(npix + 2 * tps * 128) * (4 * NS) * 16 + coef_lds;
-        const size_t tr = (size_t)ROWS * 2048 * sizeof(float);      // epilogue transpose regions alias the buffers
+        const size_t tr = (size_t)ROWS * 64 * 36 * sizeof(float);   // epilogue transpose regions alias the buffers (stride <= 36)
         return main > tr ? main : tr;
     };
+    // MFMA shape of the fp16 3x3 kernel: 16x16x32 from 8 channel chunks up (CDDPM_M16=0 / 1 forces 32x32x16 / 16x16x32)
+    static const int m16_env = [] { const char* e = getenv("CDDPM_M16"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
+    const bool m16 = (NS == 2) && (a.taps == 9) && (m16_env >= 0 ? m16_env == 1 : (a.C0 + a.C1) >= 256);
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_split_kernel<9, ROWS, NS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_split_kernel<9, ROWS, NS, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_split_kernel<1, ROWS, NS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_split_kernel<4, ROWS, NS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr = true;
     }
-    if (a.taps == 9) hipLaunchKernelGGL((conv_split_kernel<9, ROWS, NS>), dim3(grid), dim3(64 * ROWS), need((ROWS + 2) * 34), stream, a);
+    if (a.taps == 9 && m16) hipLaunchKernelGGL((conv_split_kernel<9, ROWS, NS, true>), dim3(grid), dim3(64 * ROWS), need((ROWS + 2) * 34), stream, a);
+    else if (a.taps == 9) hipLaunchKernelGGL((conv_split_kernel<9, ROWS, NS>), dim3(grid), dim3(64 * ROWS), need((ROWS + 2) * 34), stream, a);
     else if (a.taps == 1) hipLaunchKernelGGL((conv_split_kernel<1, ROWS, NS>), dim3(grid), dim3(64 * ROWS), need(ROWS * 32), stream, a);
     else hipLaunchKernelGGL((conv_split_kernel<4, ROWS, NS>), dim3(grid), dim3(64 * ROWS), need((ROWS + 1) * 33), stream, a);
 }
