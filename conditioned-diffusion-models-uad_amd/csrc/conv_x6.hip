@@ -515,7 +515,10 @@ __global__ __launch_bounds__(64 * ROWS) void conv_split_kernel(const ConvArgs a)
     // ---- epilogue: as conv_mfma.hip -- each wave transposes its 64 x 64 tile through a private 8-KB LDS region so
     //      that every lane moves 16 B; bias, residual and the GroupNorm statistics of the output are applied here.
     {
-        constexpr int TRS = M16 ? 36 : 32;                            // row stride of the transpose region (36: conflict-free for the 16 x 16 C layout)
+#ifndef CDDPM_TRS16
+#define CDDPM_TRS16 36
+#endif
+        constexpr int TRS = M16 ? CDDPM_TRS16 : 32;                            // row stride of the transpose region (36: conflict-free for the 16 x 16 C layout)
         float* tr = reinterpret_cast<float*>(lds) + wave * (64 * TRS);   // [64 pixels][32 channels]
         const int cq = lane & 7;
         const int prow = lane >> 3;
