@@ -270,6 +270,10 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(const ConvArgs a) {
             const int s_done = (grp == 0) ? s : s - 1;
             const bool do_ld = more && (tap < NK);
             const int p_ld = do_ld ? ldsPS[tap * THREADS + tid] : -1;
+            // k-step 0 fragments of the stage this wave computes next: requested FIRST -- the barrier at the end of the phase
+            // waits for every LDS operation of the wave (lgkmcnt(0)), so their round trip has to hide behind the rest
+            const int s_next = s_done + 1;
+            if (s_next < N) load_frags(s_next, 0, pa, pb);
             if (s_done >= 0 && ((s_done % TAPS) % 3) == 2) {
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
@@ -288,9 +292,6 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(const ConvArgs a) {
             for (int i = 0; i < WK; ++i) wreg[i] = slab_ptr(s + 3)[tid + THREADS * i];
             if (do_ld) ent = load_entry(chunk + 1, p_ld);
             PST(6)
-            // k-step 0 fragments of the stage this wave computes next (LDS only; nobody waits for them before the barrier)
-            const int s_next = s_done + 1;
-            if (s_next < N) load_frags(s_next, 0, pa, pb);
             PST(7)
         }
 #ifdef CDDPM_STAMPS
