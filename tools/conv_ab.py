@@ -92,6 +92,10 @@ def main():
                     env["CDDPM_CONV"] = opt
                 if opt == "pp":
                     env["CDDPM_CONV_PP"] = "1"
+                if opt in ("m16", "m32"):
+                    env["CDDPM_M16"] = "1" if opt == "m16" else "0"
+                if opt == "r4":
+                    env["CDDPM_ROWS"] = "4"
                 if opt == "zero":
                     env["CDDPM_BENCH_ZERO"] = "1"
                 if opt in ("w4", "w8"):
