@@ -143,7 +143,13 @@ __global__ __launch_bounds__(64 * ROWS, ROWS == 4 ? 2 : 1) void conv_split_kerne
     const int gridH = UP2 ? (a.H >> 1) : a.H, gridW = UP2 ? (a.W >> 1) : a.W;
     const int tilesX = (gridW + 31) >> 5;
     const int tilesY = (gridH + ROWS - 1) / ROWS;
+    // Workgroups go to the 8 XCDs round-robin (blockIdx % 8), each with its own L2. Give every XCD a CONTIGUOUS range of
+    // tiles instead: the cout blocks of one tile and the tiles above / below it (shared halo rows) then run on one XCD at
+    // about the same time, and the second reader of a patch row finds it in that L2.
     int bid = blockIdx.x;
+#ifndef CDDPM_NO_XCD_REMAP
+    if ((gridDim.x & 7) == 0) bid = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+#endif
     const int cb = bid % ncb;
     bid /= ncb;
     const int tx = bid % tilesX;

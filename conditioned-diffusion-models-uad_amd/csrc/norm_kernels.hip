@@ -90,7 +90,16 @@ __global__ __launch_bounds__(512) void gn_finalize_kernel(const float* __restric
         double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
         if (rl < nrl) {
             const float* base = rec + ((size_t)b * ns) * Cs * 2 + 4 * cp;
-            for (int r = rl; r < ns; r += nrl) {
+            // eight records in flight per thread (the loop is latency-bound: one workgroup per sample); same summation order
+            int r = rl;
+            for (; r + 7 * nrl < ns; r += 8 * nrl) {
+                float4 v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const float4*>(base + (size_t)(r + j * nrl) * Cs * 2);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { a0 += v[j].x; a1 += v[j].y; a2 += v[j].z; a3 += v[j].w; }
+            }
+            for (; r < ns; r += nrl) {
                 const float4 v = *reinterpret_cast<const float4*>(base + (size_t)r * Cs * 2);
                 a0 += v.x; a1 += v.y; a2 += v.z; a3 += v.w;
             }
