@@ -92,7 +92,7 @@ __device__ __forceinline__ void split_x4(const v4f v, typename SplitT<NS>::v4 (&
 // wave) instead of 32x32x16: the same cycle count, but the chip holds a higher clock on this shape -- the default of the
 // fp16 form (the 32x32x16 instances stay for CDDPM_M16=0); half as many accumulate roundings per product.
 template <int TAPS, int ROWS, int NS, bool M16X = false>
-__global__ __launch_bounds__(64 * ROWS, ROWS == 4 ? 2 : 1) void conv_split_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(64 * ROWS) void conv_split_kernel(const ConvArgs a) {
     typedef typename SplitT<NS>::v8 frag;
     constexpr int SP = 4 * NS;                          // 16-B slots per pixel / per cout row
     constexpr int THREADS = 64 * ROWS;
@@ -114,9 +114,7 @@ __global__ __launch_bounds__(64 * ROWS, ROWS == 4 ? 2 : 1) void conv_split_kerne
     // taps per weight stage: the fp16 form stages a whole row of taps (3 of the 3x3, 2 of the folded 2x2) per workgroup
     // barrier -- one barrier (and one burst of fragment reads behind it) per 72 MFMAs of a wave instead of per 24, and the
     // stage is exactly one accumulation group (FOLD taps). The bf16 form's slabs are 1.5x larger: one tap per stage.
-    // ROWS == 4 (four waves, 128 pixels): two workgroups share a CU -- one transforms its patch while the other multiplies --
-    // so the stage is one tap (2 x 16 KB of weights) and a workgroup stays under half the LDS.
-    constexpr int TPS = (NS == 2 && ROWS == 8) ? FOLD : 1;
+    constexpr int TPS = (NS == 2) ? FOLD : 1;
     constexpr int WSTAGE = TPS * WSLOTS;                // 16-B slots of one weight stage
     constexpr int WK = WSLOTS / THREADS;                // 16-B pieces of ONE slab per thread: 3 | 2
     static_assert(WSLOTS % THREADS == 0, "weight slab must divide evenly");
@@ -168,15 +166,17 @@ __global__ __launch_bounds__(64 * ROWS, ROWS == 4 ? 2 : 1) void conv_split_kerne
     // ... of the patch in the fp16 form. The weight image above is fixed by the host packer; the patch is written here, so
     // its swizzle follows the reads: a ds_read_b128 is served in four groups of 16 lanes ({0-3,12-15,20-27}, {4-11,16-19,
     // 28-31}, +32) over 64 banks of 4 B, a ds_write_b64 in 16 consecutive lanes over 32 banks (MI355X_MICROARCH.md, LDS).
-    //   32x32x16: a group reads 16 consecutive pixels at one u  -> row bits 1..3 into the slot (as the weights), and row
+    //   32x32x16: a group reads 16 consecutive pixels at one u  -> pixel bits 1..3 into the slot (as the weights), and pixel
     //             bit 0 flips the split half so that the two pixels one store instruction covers do not share banks;
     //   16x16x32: a group reads 8 + 8 pixels at u and u ^ 1, from ANY start pixel (tap shifts) -> slot bit 0 must stay u's,
-    //             so only bits 1, 2 are swizzled (by pixel bits 1, 2, and bit 2 by pixel bit 0 as above).
+    //             so only bits 1, 2 are swizzled -- by the pixel's COLUMN in the patch (bits 1, 2 -> slot bit 1, 2; bit 0 ->
+    //             slot bit 2; the patch width is even, so column and pixel parity agree): a tap's row shift ky is then a
+    //             plain address offset and the fragment addresses are computed once per kernel, not once per tap.
     // Both are conflict-free for every tap; with the weights' swizzle the 16x16 reads took 7 LDS cycles instead of 4.
     constexpr bool M16S = M16X && (NS == 2);
-    auto slot_a = [](int row, int sp, int u) -> int {
+    auto swz16 = [](int pc) -> int { return (2 * ((pc >> 1) & 3)) ^ (4 * (pc & 1)); };
+    auto slot_a = [](int row, int sp, int u) -> int {      // (not the 16x16 form)
         if (NS == 3) return row * 12 + 4 * sp + (u ^ ((row >> 2) & 3));
-        if (M16S) return row * 8 + ((4 * sp + u) ^ (2 * ((row >> 1) & 3)) ^ (4 * (row & 1)));
         return row * 8 + ((4 * sp + u) ^ ((row >> 1) & 7) ^ (4 * (row & 1)));
     };
 
@@ -189,10 +189,12 @@ __global__ __launch_bounds__(64 * ROWS, ROWS == 4 ? 2 : 1) void conv_split_kerne
     const int c4 = tid & 7;
     int psrc[NK];
     unsigned centre = 0;
+    unsigned colswz = 0;                 // 16x16 form: swz16(column) of entry k in bits 3k .. 3k+2
 #pragma unroll
     for (int k = 0; k < NK; ++k) {
         const int q = (tid >> 3) + (THREADS / 8) * k;
         const int pr = q / PW, pc = q - pr * PW;
+        if constexpr (M16S) colswz |= (unsigned)swz16(pc) << (3 * k);
         const int y = UP2 ? (y0 + pr + pa - 1) : (y0 + pr - PAD), x = UP2 ? (x0 + pc + pb - 1) : (x0 + pc - PAD);
         const bool valid = (q < NPIX) && (y >= 0) && (y < gridH) && (x >= 0) && (x < gridW);
         const int sy = (!UP2 && a.upsample) ? (y >> 1) : y, sx = (!UP2 && a.upsample) ? (x >> 1) : x;
@@ -259,7 +261,10 @@ __global__ __launch_bounds__(64 * ROWS, ROWS == 4 ? 2 : 1) void conv_split_kerne
                 split_x4<NS>(v, t);
                 // 4 channels = half a slot: slot u = c4 >> 1 of each split, half c4 & 1
 #pragma unroll
-                for (int sp = 0; sp < NS; ++sp) dst[slot_a(q, sp, c4 >> 1) * 2 + (c4 & 1)] = __builtin_bit_cast(v2f, t[sp]);
+                for (int sp = 0; sp < NS; ++sp) {
+                    const int sl = M16S ? (q * 8 + ((4 * sp + (c4 >> 1)) ^ (int)((colswz >> (3 * k)) & 7u))) : slot_a(q, sp, c4 >> 1);
+                    dst[sl * 2 + (c4 & 1)] = __builtin_bit_cast(v2f, t[sp]);
+                }
             }
         }
     };
@@ -300,30 +305,48 @@ __global__ __launch_bounds__(64 * ROWS, ROWS == 4 ? 2 : 1) void conv_split_kerne
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) brow[nt] = 64 * wn + 32 * nt + li;
 
-    // `first`: the accumulators restart here (C = 0 in the first MFMA of each tile, no register clearing)
-    auto compute = [&](int tap, const v4f* wb, bool first) {
+    // 16 x 16 form: fragment slots, once per kernel. Lane (r = lane & 15, g = lane >> 4) holds row r, channels 8 g .. 8 g + 7
+    // of a 16 x 32 operand tile. abase[kx][t16]: the hi-term slot of pixel group t16 shifted by kx columns (the mid term is
+    // 4 slots away under XOR; a tap's ky adds ky * PW * 8); bbase[n]: cout group n of this wave in a weight slab.
+    constexpr int NKX = (TAPS == 9) ? 3 : (UP2 ? 2 : 1);
+    static_assert(!M16 || TPS == NKX, "16x16 form: a weight stage is one row of taps, so the column shift is the unrolled index");
+    int abase[NKX][4], bbase[4];
+    if constexpr (M16) {
+        const int r16 = lane & 15, g = lane >> 4;
+#pragma unroll
+        for (int kx = 0; kx < NKX; ++kx)
+#pragma unroll
+            for (int t16 = 0; t16 < 4; ++t16) {
+                const int pc = (t16 & 1) * 16 + r16 + kx;
+                abase[kx][t16] = ((2 * wm + (t16 >> 1)) * PW + pc) * 8 + (g ^ swz16(pc));
+            }
+#pragma unroll
+        for (int n = 0; n < 4; ++n) bbase[n] = slot_of(64 * wn + 16 * n + r16, 0, g);
+    }
+
+    // `first`: the accumulators restart here (C = 0 in the first MFMA of each tile, no register clearing).
+    // kxc: the tap's column shift where the caller knows it at compile time (16 x 16 form: it selects registers); skip: the
+    // 1x1 skip segment (centre tap).
+    auto compute = [&](int tap, int kxc, bool skip, const v4f* wb, bool first) {
         const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         const int ky = (TAPS == 9) ? (tap / 3) : (UP2 ? (tap >> 1) : 0);
         const int kx = (TAPS == 9) ? (tap - 3 * ky) : (UP2 ? (tap & 1) : 0);
         if constexpr (M16) {
-            // lane (r = lane & 15, g = lane >> 4) holds row r, channels 8 g .. 8 g + 7 of a 16 x 32 operand tile
-            const int r16 = lane & 15, g = lane >> 4;
             const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
             f16x8 fa[2][4];
 #pragma unroll
             for (int t16 = 0; t16 < 4; ++t16) {
-                const int arow = (2 * wm + (t16 >> 1) + ky) * PW + (t16 & 1) * 16 + r16 + kx;
-#pragma unroll
-                for (int sp = 0; sp < 2; ++sp) fa[sp][t16] = __builtin_bit_cast(f16x8, ldsA[slot_a(arow, sp, g)]);
+                const int s0 = ((TAPS == 9 && skip) ? abase[NKX / 2][t16] : abase[kxc][t16]) + ky * (PW * 8);
+                fa[0][t16] = __builtin_bit_cast(f16x8, ldsA[s0]);
+                fa[1][t16] = __builtin_bit_cast(f16x8, ldsA[s0 ^ 4]);
             }
 #pragma unroll
             for (int nh = 0; nh < 2; ++nh) {            // two cout 16-groups at a time: 12 fragments live instead of 16
                 f16x8 fb[2][2];
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    const int browm = 64 * wn + 16 * (2 * nh + j) + r16;
-#pragma unroll
-                    for (int sp = 0; sp < 2; ++sp) fb[sp][j] = __builtin_bit_cast(f16x8, wb[slot_of(browm, sp, g)]);
+                    fb[0][j] = __builtin_bit_cast(f16x8, wb[bbase[2 * nh + j]]);
+                    fb[1][j] = __builtin_bit_cast(f16x8, wb[bbase[2 * nh + j] ^ 4]);
                 }
 #pragma unroll
                 for (int p = 0; p < 3; ++p) {       // mid*hi, hi*mid, hi*hi
@@ -421,7 +444,7 @@ __global__ __launch_bounds__(64 * ROWS, ROWS == 4 ? 2 : 1) void conv_split_kerne
             // (<= 96 products per chain), `tot` sums those groups. The rounding noise of an fp32 chain grows with the
             // magnitude of its partial sums, so short chains folded into a long-lived total keep it near the
             // storage-rounding level (tools/ubench/bf16_split_accuracy.hip, tools/chain_noise.py).
-            compute(main_seg ? t : (TAPS / 2), ldsW + buf * WSLOTS, (t % FOLD) == 0);   // skip segment: centre tap
+            compute(main_seg ? t : (TAPS / 2), 0, !main_seg, ldsW + buf * WSLOTS, (t % FOLD) == 0);   // skip segment: centre tap (16x16 form: 1x1 convolutions only get here)
             buf ^= 1;
             STAMP(3)
             if ((t % FOLD) == FOLD - 1 || last_tap) {
@@ -493,7 +516,7 @@ __global__ __launch_bounds__(64 * ROWS, ROWS == 4 ? 2 : 1) void conv_split_kerne
             for (int tt = 0; tt < TPS; ++tt)
                 if (tt < ntaps) {
                     const int t = st * TPS + tt;                                  // tap index inside the chunk
-                    compute(main_seg ? t : (TAPS / 2), ldsW + buf * WSTAGE + tt * WSLOTS, (t % FOLD) == 0);   // skip segment: centre tap
+                    compute(main_seg ? t : (TAPS / 2), tt, !main_seg, ldsW + buf * WSTAGE + tt * WSLOTS, (t % FOLD) == 0);   // skip segment: centre tap
                 }
             buf ^= 1;
             nsl_cur = nsl_next;
@@ -576,7 +599,7 @@ __global__ __launch_bounds__(64 * ROWS, ROWS == 4 ? 2 : 1) void conv_split_kerne
             for (int tt = 0; tt < TPS; ++tt)
                 if (TPS == 1 || tt < ntaps) {
                     const int t = st * TPS + tt;                                  // tap index inside the chunk
-                    compute(main_seg ? t : (TAPS / 2), ldsW + buf * WSTAGE + tt * WSLOTS, (t % FOLD) == 0);   // skip segment: centre tap
+                    compute(main_seg ? t : (TAPS / 2), tt, !main_seg, ldsW + buf * WSTAGE + tt * WSLOTS, (t % FOLD) == 0);   // skip segment: centre tap
                 }
             buf ^= 1;
             STAMP(3)
@@ -722,7 +745,7 @@ static void launch_split(const ConvArgs& a, hipStream_t stream) {
     const unsigned grid = (unsigned)(a.B * (up2 ? 4 : 1) * tilesX * tilesY * (a.Cout / 128));
     const size_t coef_lds = a.coef ? (size_t)3 * (a.C0 + a.C1) * sizeof(float) : 0;
     auto need = [&](int npix) {
-        const int tps = (NS == 2 && ROWS == 8) ? (a.taps == 9 ? 3 : (a.taps == 4 ? 2 : 1)) : 1;     // taps per weight stage (kernel: TPS)
+        const int tps = (NS == 2) ? (a.taps == 9 ? 3 : (a.taps == 4 ? 2 : 1)) : 1;     // taps per weight stage (kernel: TPS)
         const size_t main = (size_t)(npix + 2 * tps * 128) * (4 * NS) * 16 + coef_lds;
         const size_t tr = (size_t)ROWS * 64 * 36 * sizeof(float);   // epilogue transpose regions alias the buffers (stride <= 36)
         return main > tr ? main : tr;
@@ -756,10 +779,7 @@ static void launch_split(const ConvArgs& a, hipStream_t stream) {
 
 void launch_conv_split(const ConvArgs& a, hipStream_t stream) {
     if (conv_mode() == 2 && conv_pp_applicable(a)) { launch_conv_pp(a, stream); return; }
-    // CDDPM_ROWS=4: 128-pixel tiles, four waves, two workgroups per CU (fp16 form)
-    static const int rows4 = [] { const char* e = getenv("CDDPM_ROWS"); return (e && e[0] == '4') ? 1 : 0; }();
     if (conv_mode() == 1) launch_split<3, 8>(a, stream);
-    else if (rows4) launch_split<2, 4>(a, stream);
     else launch_split<2, 8>(a, stream);
 }
 
