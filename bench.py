@@ -193,7 +193,7 @@ def main():
             nprod = 3.0 if CONV_MODE == "h3" else 6.0
             kern = ("conv_split_kernel<9,8,%d> and <4,8,%d> (fused GN/FiLM/SiLU + 3x3 conv [+ folded upsample] + skip + GN statistics; "
                     "fp32 operands as %s, %d %s per product group, fp32 accumulate); achieved = executed 16-bit-pipe FLOPs = %d x algorithmic"
-                    % ((2, 2, "2 fp16 terms", 3, "v_mfma_f32_32x32x16_f16", 3) if CONV_MODE == "h3"
+                    % ((2, 2, "2 fp16 terms", 3, "v_mfma_f32_16x16x32_f16", 3) if CONV_MODE == "h3"
                        else (3, 3, "3 bf16 terms", 6, "v_mfma_f32_32x32x16_bf16", 6)))
             roof = {"achieved": nprod * ach, "peak": PEAK_BF16_MFMA_TFLOPS, "frac": nprod * ach / PEAK_BF16_MFMA_TFLOPS,
                     "fp32_equivalent_tflops": ach, "fp32_mfma_peak": PEAK_FP32_MFMA_TFLOPS,

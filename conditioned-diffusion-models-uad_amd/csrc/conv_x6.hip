@@ -76,6 +76,25 @@ __device__ __forceinline__ float silu_x6(float v) {
     return v * __builtin_amdgcn_rcpf(1.0f + e);
 }
 
+// the same on four values, written on vectors so that the multiplies / fmas / adds issue as packed (v_pk_*_f32) instructions:
+// 26 VALU instructions per quad instead of 46. Identical results for x > -87.3; below, where the exponent clamps, the
+// correction term is left to run (it only pushes e further towards +inf and the result towards the limit 0).
+__device__ __forceinline__ v4f silu_x6_v4(const v4f v) {
+    const v4f nl2e = {-1.44269502162933349609375f, -1.44269502162933349609375f, -1.44269502162933349609375f, -1.44269502162933349609375f};
+    const v4f nl2e_lo = {-1.925963033500011e-08f, -1.925963033500011e-08f, -1.925963033500011e-08f, -1.925963033500011e-08f};
+    const v4f lim = {126.0f, 126.0f, 126.0f, 126.0f};
+    const v4f ln2 = {0.693147180559945f, 0.693147180559945f, 0.693147180559945f, 0.693147180559945f};
+    const v4f one = {1.0f, 1.0f, 1.0f, 1.0f};
+    const v4f t = __builtin_elementwise_min(v * nl2e, lim);
+    v4f tl = __builtin_elementwise_fma(v, nl2e, -t);
+    tl = __builtin_elementwise_fma(v, nl2e_lo, tl);
+    v4f e = {__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y), __builtin_amdgcn_exp2f(t.z), __builtin_amdgcn_exp2f(t.w)};
+    e = __builtin_elementwise_fma(e, tl * ln2, e);
+    const v4f d = one + e;
+    const v4f r = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z), __builtin_amdgcn_rcpf(d.w)};
+    return v * r;
+}
+
 // split of four fp32 values into NS 16-bit quads (8 B each): t[0] = cvt(v), t[1] = cvt(v - t[0]), ...
 template <int NS>
 __device__ __forceinline__ void split_x4(const v4f v, typename SplitT<NS>::v4 (&t)[NS]) {
@@ -198,7 +217,7 @@ __global__ __launch_bounds__(64 * ROWS) void conv_split_kernel(const ConvArgs a)
         const int y = UP2 ? (y0 + pr + pa - 1) : (y0 + pr - PAD), x = UP2 ? (x0 + pc + pb - 1) : (x0 + pc - PAD);
         const bool valid = (q < NPIX) && (y >= 0) && (y < gridH) && (x >= 0) && (x < gridW);
         const int sy = (!UP2 && a.upsample) ? (y >> 1) : y, sx = (!UP2 && a.upsample) ? (x >> 1) : x;
-        psrc[k] = valid ? ((b * a.srcH + sy) * a.srcW + sx) : -1;
+        psrc[k] = valid ? (sy * a.srcW + sx) : -1;           // pixel index inside sample b (< 2^24)
         if (valid && (pr >= PAD) && (pr < PH - PAD) && (pc >= PAD) && (pc < PW - PAD)) centre |= 1u << k;
     }
 
@@ -227,11 +246,13 @@ __global__ __launch_bounds__(64 * ROWS) void conv_split_kernel(const ConvArgs a)
             if (ch < a.S0) { base = a.skip0; Cs = a.S0; c0 = ch; }
             else           { base = a.skip1; Cs = a.S1; c0 = ch - a.S0; }
         }
+        const float* ubase = base + ((size_t)b * a.srcH * a.srcW * Cs + c0);
 #pragma unroll
         for (int k = 0; k < NK; ++k) {
             const int p = (main_seg || ((centre >> k) & 1u)) ? psrc[k] : -1;
             v4f v = v4f{0.f, 0.f, 0.f, 0.f};
-            if (p >= 0) v = *reinterpret_cast<const v4f*>(base + (size_t)p * Cs + c0 + 4 * c4);
+            // wave-uniform 64-bit base (sample, channel chunk) + a 32-bit per-lane offset: one v_mad_u32_u24 per entry
+            if (p >= 0) v = *reinterpret_cast<const v4f*>(ubase + (__umul24((unsigned)p, (unsigned)Cs) + 4u * (unsigned)c4));
             areg[k] = v;
         }
     };
@@ -252,8 +273,11 @@ __global__ __launch_bounds__(64 * ROWS) void conv_split_kernel(const ConvArgs a)
             v4f v = areg[k];
             const int p = (main_seg || ((centre >> k) & 1u)) ? psrc[k] : -1;
             if (p >= 0) {   // zero padding stays exactly zero: the conv pads AFTER the activation
-                if (aff) v = (v - cm) * ca + cd;
-                if (do_silu) { v.x = silu_x6(v.x); v.y = silu_x6(v.y); v.z = silu_x6(v.z); v.w = silu_x6(v.w); }
+                v = (v - cm) * ca + cd;         // (identity coefficients where there is no GroupNorm: exact, and no select)
+                if (do_silu) {
+                    if constexpr (NS == 2) v = silu_x6_v4(v);
+                    else { v.x = silu_x6(v.x); v.y = silu_x6(v.y); v.z = silu_x6(v.z); v.w = silu_x6(v.w); }
+                }
             }
             const int q = (tid >> 3) + (THREADS / 8) * k;
             if (q < NPIX) {
