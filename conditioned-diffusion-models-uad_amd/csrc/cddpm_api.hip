@@ -209,6 +209,9 @@ int validate_desc(cddpm_ctx* h, const cddpm_unet_desc* d) {
     const int q = 1 << (d->num_levels - 1);
     if (d->max_batch < 1 || d->max_h < q || d->max_w < q || d->max_h % q || d->max_w % q || d->max_h % 4 || d->max_w % 4)
         return fail(h, "max_batch/max_h/max_w invalid (H, W must be multiples of %d and of 4)", q > 4 ? q : 4);
+    // pixel indices are 32-bit in the small kernels and inside a sample in the convolutions
+    if ((long long)d->max_batch * d->max_h * d->max_w >= (1ll << 30) || (long long)d->max_h * d->max_w >= (1ll << 24))
+        return fail(h, "max_batch * max_h * max_w must stay below 2^30 pixels (and one slice below 2^24): split the batch");
     return 0;
 }
 

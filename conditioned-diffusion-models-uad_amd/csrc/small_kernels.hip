@@ -36,13 +36,15 @@ __global__ __launch_bounds__(256) void conv_in1_kernel(const float* __restrict__
 #pragma unroll
         for (int t = 0; t < 9; ++t) wr[i][t] = w[(4 * cq + i) * 9 + t];
     }
-    const long long total = (long long)B * H * W;
-    const int ppb = 64 * npl;   // pixels per block
-    for (long long p = (long long)blockIdx.x * ppb + pl; p < min(total, (long long)(blockIdx.x + 1) * ppb); p += npl) {
-        const int xx = (int)(p % W);
-        const int yy = (int)((p / W) % H);
-        const long long bb = p / ((long long)W * H);
-        const float* img = x + bb * H * W;
+    const unsigned total = (unsigned)B * H * W;     // < 2^31 (checked by the launcher): 32-bit divisions, not 64-bit ones
+    const unsigned ppb = 64u * npl;   // pixels per block
+    const unsigned pend = min(total, (blockIdx.x + 1u) * ppb);
+    for (unsigned p = blockIdx.x * ppb + pl; p < pend; p += npl) {
+        const unsigned row = p / (unsigned)W;
+        const int xx = (int)(p - row * W);
+        const unsigned bb = row / (unsigned)H;
+        const int yy = (int)(row - bb * H);
+        const float* img = x + (size_t)bb * H * W;
         float v[9];
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky)
@@ -60,7 +62,7 @@ __global__ __launch_bounds__(256) void conv_in1_kernel(const float* __restrict__
             for (int t = 0; t < 9; ++t) acc = fmaf(v[t], wr[i][t], acc);
             op[i] = acc;
         }
-        *reinterpret_cast<float4*>(out + p * C + 4 * cq) = o;
+        *reinterpret_cast<float4*>(out + (size_t)p * C + 4 * cq) = o;
     }
 }
 
@@ -82,8 +84,8 @@ __global__ __launch_bounds__(256) void head_dots_kernel(const float* __restrict_
                                                         const float* __restrict__ w9, float* __restrict__ P, int B,
                                                         int HW, int C) {
     extern __shared__ float hl[];
-    float* lx = hl;                    // [64][C+1]
-    float* lw = hl + 64 * (C + 1);     // [9][C]
+    float* lx = hl;                    // [64][C+4]: 16-B aligned rows, 64 lanes x b128 conflict-free (row stride = 4 banks mod 64)
+    float* lw = hl + 64 * (C + 4);     // [9][C]
     const int tid = threadIdx.x;
     const long long total = (long long)B * HW;
     const long long pix0 = (long long)blockIdx.x * 64;
@@ -106,8 +108,7 @@ __global__ __launch_bounds__(256) void head_dots_kernel(const float* __restrict_
             v.z = silu_s((v.z - m.z) * a.z + d.z);
             v.w = silu_s((v.w - m.w) * a.w + d.w);
         }
-        float* dst = lx + pl * (C + 1) + 4 * cq;
-        dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+        *reinterpret_cast<float4*>(lx + pl * (C + 4) + 4 * cq) = v;
     }
     __syncthreads();
     const int pl = tid & 63;
@@ -115,9 +116,15 @@ __global__ __launch_bounds__(256) void head_dots_kernel(const float* __restrict_
     const long long p = pix0 + pl;
     for (int tap = tg; tap < 9; tap += 4) {
         float acc = 0.f;
-        const float* xr = lx + pl * (C + 1);
-        const float* wr = lw + tap * C;
-        for (int c = 0; c < C; ++c) acc = fmaf(xr[c], wr[c], acc);
+        const float4* xr = reinterpret_cast<const float4*>(lx + pl * (C + 4));
+        const float4* wr = reinterpret_cast<const float4*>(lw + tap * C);      // wave-uniform: broadcast reads
+        for (int c = 0; c < (C >> 2); ++c) {       // same summation order as one fma per channel
+            const float4 xv = xr[c], wv = wr[c];
+            acc = fmaf(xv.x, wv.x, acc);
+            acc = fmaf(xv.y, wv.y, acc);
+            acc = fmaf(xv.z, wv.z, acc);
+            acc = fmaf(xv.w, wv.w, acc);
+        }
         if (p < total) P[p * 9 + tap] = acc;
     }
 }
@@ -125,7 +132,7 @@ __global__ __launch_bounds__(256) void head_dots_kernel(const float* __restrict_
 void launch_head_dots(const float* x, const float* coef, const float* w9, float* P, int B, int HW, int C,
                       hipStream_t stream) {
     const long long total = (long long)B * HW;
-    const size_t lds = (size_t)(64 * (C + 1) + 9 * C) * sizeof(float);
+    const size_t lds = (size_t)(64 * (C + 4) + 9 * C) * sizeof(float);
     hipLaunchKernelGGL(head_dots_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), lds, stream, x, coef, w9, P, B,
                        HW, C);
 }
