@@ -110,6 +110,10 @@ struct cddpm_ctx {
     bool profiling = false;
     std::vector<ProfRec> prof;
     std::vector<hipEvent_t> ev_pool;
+    // consecutive launches on one stream share an event: the end of one is the begin of the next (half the event records
+    // in the stream; a launch's time then includes the few-microsecond gap in front of it)
+    hipEvent_t prof_last = nullptr;
+    hipStream_t prof_last_stream = nullptr;
 };
 
 namespace {
@@ -136,13 +140,16 @@ struct Prof {
     }
     Prof(cddpm_ctx* h_, int cls, double flops, double bytes, hipStream_t s_) : h(h_), s(s_), on(h_->profiling) {
         if (!on) return;
-        r.cls = cls; r.flops = flops; r.bytes = bytes; r.a = ev(h); r.b = ev(h);
-        (void)hipEventRecord(r.a, s);
+        r.cls = cls; r.flops = flops; r.bytes = bytes; r.b = ev(h);
+        if (h->prof_last && h->prof_last_stream == s) r.a = h->prof_last;
+        else { r.a = ev(h); (void)hipEventRecord(r.a, s); }
     }
     ~Prof() {
         if (!on) return;
         (void)hipEventRecord(r.b, s);
         h->prof.push_back(r);
+        h->prof_last = r.b;
+        h->prof_last_stream = s;
     }
 };
 
@@ -688,7 +695,8 @@ void cddpm_destroy(cddpm_handle h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     for (void* p : h->allocs) (void)hipFree(p);
-    for (auto& r : h->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    { hipEvent_t shared = nullptr;
+      for (auto& r : h->prof) { if (r.a != shared) (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); shared = r.b; } }
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
     delete h;
 }
@@ -983,6 +991,7 @@ int cddpm_q_sample(cddpm_handle h, const float* x01_dev, const float* noise_dev,
 int cddpm_set_profiling(cddpm_handle h, int on) {
     if (!h) return -1;
     h->profiling = on != 0;
+    h->prof_last = nullptr;
     return 0;
 }
 
@@ -992,14 +1001,17 @@ int cddpm_get_profile(cddpm_handle h, int ncls, double* ms, double* flops, doubl
     HIPCHECK(h, hipSetDevice(h->device));
     HIPCHECK(h, hipDeviceSynchronize());
     for (int i = 0; i < PC_COUNT; ++i) { ms[i] = 0; flops[i] = 0; bytes[i] = 0; launches[i] = 0; }
+    hipEvent_t shared = nullptr;
     for (auto& r : h->prof) {
         float t = 0.f;
         HIPCHECK(h, hipEventElapsedTime(&t, r.a, r.b));
         ms[r.cls] += t; flops[r.cls] += r.flops; bytes[r.cls] += r.bytes; launches[r.cls] += 1;
-        h->ev_pool.push_back(r.a);
+        if (r.a != shared) h->ev_pool.push_back(r.a);      // (a shared begin event is the previous record's end event)
         h->ev_pool.push_back(r.b);
+        shared = r.b;
     }
     h->prof.clear();
+    h->prof_last = nullptr;
     return 0;
 }
 
