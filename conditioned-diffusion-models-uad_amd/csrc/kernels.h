@@ -97,6 +97,7 @@ void launch_pool_act(const float* x, const float* coef, float* hp, float* xp, in
 void launch_linear(const float* x, int ldx, const float* W, int ldw, int koff, const float* bias, float* y, int ldy,
                    int M, int N, int K, int silu_in, hipStream_t stream);
 void launch_fill_int(int* p, int n, int v, hipStream_t stream);
+void launch_add_int(int* p, int n, int v, hipStream_t stream);
 
 // posterior step (cond_DDPM.py:391-444): x <- c1[t] * x0hat + c2[t] * x + exp(0.5 logvar[t]) * z (t > 0)
 struct StepArgs {
@@ -104,9 +105,10 @@ struct StepArgs {
     const float* coef1; const float* coef2; const float* logvar; const float* sqrt_recip; const float* sqrt_recipm1;
     int objective;
     const float* noise;          // explicit z for this step [B,HW] or nullptr -> Philox
+    size_t noise_t_stride;       // 0, or (graph replay: `noise` is the base of a [T][B][HW] array) the stride of its t axis
     uint64_t seed, slice0; int t_for_rng;
     int B, HW;
-    int finalize;                // 1: also map to [0,1]: (x+1)/2 (cond_DDPM.py:463)
+    int finalize;                // 1: also map to [0,1]: (x+1)/2 (cond_DDPM.py:463); -1: exactly when t == 0 (graph replay)
 };
 void launch_step(const StepArgs& a, hipStream_t stream);
 // DDIM step (cond_DDPM.py:487-511): eps = (sqrt_recip[t] x - x0) / sqrt_recipm1[t] from the UNCLIPPED x0 (pred_x0 objective;

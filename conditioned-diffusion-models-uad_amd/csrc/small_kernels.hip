@@ -248,6 +248,13 @@ __global__ void fill_int_kernel(int* p, int n, int v) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < n) p[i] = v;
 }
+__global__ void add_int_kernel(int* p, int n, int v) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] += v;
+}
+void launch_add_int(int* p, int n, int v, hipStream_t stream) {
+    hipLaunchKernelGGL(add_int_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, p, n, v);
+}
 void launch_fill_int(int* p, int n, int v, hipStream_t stream) {
     hipLaunchKernelGGL(fill_int_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, p, n, v);
 }
@@ -340,14 +347,14 @@ __global__ __launch_bounds__(256) void step_kernel(const StepArgs a) {
     if (t > 0) {
         const float sigma = expf(0.5f * a.logvar[t]);
         float4 z;
-        if (a.noise) z = *reinterpret_cast<const float4*>(a.noise + off);
+        if (a.noise) z = *reinterpret_cast<const float4*>(a.noise + (size_t)t * a.noise_t_stride + off);
         else z = normal4((uint32_t)q, (uint32_t)t, (uint32_t)(a.slice0 + b), 0x1002u, a.seed);
         r.x = __fadd_rn(r.x, __fmul_rn(sigma, z.x));
         r.y = __fadd_rn(r.y, __fmul_rn(sigma, z.y));
         r.z = __fadd_rn(r.z, __fmul_rn(sigma, z.z));
         r.w = __fadd_rn(r.w, __fmul_rn(sigma, z.w));
     }
-    if (a.finalize) {
+    if (a.finalize < 0 ? (t == 0) : (a.finalize != 0)) {
         r.x = (r.x + 1.f) * 0.5f; r.y = (r.y + 1.f) * 0.5f; r.z = (r.z + 1.f) * 0.5f; r.w = (r.w + 1.f) * 0.5f;
     }
     *reinterpret_cast<float4*>(a.x + off) = r;
