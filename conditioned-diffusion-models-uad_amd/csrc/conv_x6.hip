@@ -330,22 +330,23 @@ __global__ __launch_bounds__(64 * ROWS) void conv_split_kernel(const ConvArgs a)
     for (int nt = 0; nt < 2; ++nt) brow[nt] = 64 * wn + 32 * nt + li;
 
     // 16 x 16 form: fragment slots, once per kernel. Lane (r = lane & 15, g = lane >> 4) holds row r, channels 8 g .. 8 g + 7
-    // of a 16 x 32 operand tile. abase[kx][t16]: the hi-term slot of pixel group t16 shifted by kx columns (the mid term is
-    // 4 slots away under XOR; a tap's ky adds ky * PW * 8); bbase[n]: cout group n of this wave in a weight slab.
+    // of a 16 x 32 operand tile. The column swizzle only looks at column bits 0..2 and the weight swizzle at cout bits 1..3,
+    // so the four pixel groups (two rows x two 16-column halves) and the four cout groups of a wave sit at CONSTANT slot
+    // offsets from the first one: one hi-term and one mid-term base (4 slots away under XOR) per column shift kx and one
+    // pair for the weights; everything else is an instruction offset. A tap's ky adds ky * PW * 8 slots.
     constexpr int NKX = (TAPS == 9) ? 3 : (UP2 ? 2 : 1);
     static_assert(!M16 || TPS == NKX, "16x16 form: a weight stage is one row of taps, so the column shift is the unrolled index");
-    int abase[NKX][4], bbase[4];
+    int a_hi[NKX], a_mid[NKX], b_hi = 0, b_mid = 0;
     if constexpr (M16) {
         const int r16 = lane & 15, g = lane >> 4;
 #pragma unroll
-        for (int kx = 0; kx < NKX; ++kx)
-#pragma unroll
-            for (int t16 = 0; t16 < 4; ++t16) {
-                const int pc = (t16 & 1) * 16 + r16 + kx;
-                abase[kx][t16] = ((2 * wm + (t16 >> 1)) * PW + pc) * 8 + (g ^ swz16(pc));
-            }
-#pragma unroll
-        for (int n = 0; n < 4; ++n) bbase[n] = slot_of(64 * wn + 16 * n + r16, 0, g);
+        for (int kx = 0; kx < NKX; ++kx) {
+            const int pc = r16 + kx;
+            a_hi[kx] = ((2 * wm) * PW + pc) * 8 + (g ^ swz16(pc));
+            a_mid[kx] = a_hi[kx] ^ 4;
+        }
+        b_hi = slot_of(64 * wn + r16, 0, g);
+        b_mid = b_hi ^ 4;
     }
 
     // `first`: the accumulators restart here (C = 0 in the first MFMA of each tile, no register clearing).
@@ -358,19 +359,23 @@ __global__ __launch_bounds__(64 * ROWS) void conv_split_kernel(const ConvArgs a)
         if constexpr (M16) {
             const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
             f16x8 fa[2][4];
+            const v4f* ah = ldsA + (((TAPS == 9 && skip) ? a_hi[NKX / 2] : a_hi[kxc]) + ky * (PW * 8));
+            const v4f* am = ldsA + (((TAPS == 9 && skip) ? a_mid[NKX / 2] : a_mid[kxc]) + ky * (PW * 8));
+            const v4f* bh = wb + b_hi;
+            const v4f* bm = wb + b_mid;
 #pragma unroll
             for (int t16 = 0; t16 < 4; ++t16) {
-                const int s0 = ((TAPS == 9 && skip) ? abase[NKX / 2][t16] : abase[kxc][t16]) + ky * (PW * 8);
-                fa[0][t16] = __builtin_bit_cast(f16x8, ldsA[s0]);
-                fa[1][t16] = __builtin_bit_cast(f16x8, ldsA[s0 ^ 4]);
+                const int off = ((t16 >> 1) * PW + (t16 & 1) * 16) * 8;      // compile-time: an instruction offset
+                fa[0][t16] = __builtin_bit_cast(f16x8, ah[off]);
+                fa[1][t16] = __builtin_bit_cast(f16x8, am[off]);
             }
 #pragma unroll
             for (int nh = 0; nh < 2; ++nh) {            // two cout 16-groups at a time: 12 fragments live instead of 16
                 f16x8 fb[2][2];
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    fb[0][j] = __builtin_bit_cast(f16x8, wb[bbase[2 * nh + j]]);
-                    fb[1][j] = __builtin_bit_cast(f16x8, wb[bbase[2 * nh + j] ^ 4]);
+                    fb[0][j] = __builtin_bit_cast(f16x8, bh[128 * (2 * nh + j)]);
+                    fb[1][j] = __builtin_bit_cast(f16x8, bm[128 * (2 * nh + j)]);
                 }
 #pragma unroll
                 for (int p = 0; p < 3; ++p) {       // mid*hi, hi*mid, hi*hi
@@ -489,16 +494,17 @@ __global__ __launch_bounds__(64 * ROWS) void conv_split_kernel(const ConvArgs a)
         nsl = 1;
         return wskip + (size_t)(chunk - nch_main) * WSLOTS;
     };
+    // Each wave copies one contiguous eighth of a slab (2 KB = two 1-KB wave-instructions) per slab of the stage. The pieces of
+    // a slab share one address pair: the instruction's immediate offset advances the global and the LDS address alike.
+    static_assert(THREADS == 512 && WSLOTS == 1024, "one slab = 8 waves x 2 KB");
     auto dma_stage = [&](const v4f* p, int nsl, int buf) {
+        const v4f* g0 = p + wave * 128 + lane;
+        v4f* d0 = ldsW + buf * WSTAGE + wave * 128;          // wave-uniform; lane l lands 16 l bytes further
 #pragma unroll
         for (int sl = 0; sl < TPS; ++sl)
             if (sl < nsl) {
-#pragma unroll
-                for (int i = 0; i < WK; ++i) {
-                    const v4f* g = p + sl * WSLOTS + tid + THREADS * i;
-                    v4f* d = ldsW + buf * WSTAGE + sl * WSLOTS + THREADS * i + (tid & ~63);   // wave-uniform; lane l lands 16 l bytes further
-                    __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)d, 16, 0, 0);
-                }
+                __builtin_amdgcn_global_load_lds((gptr_t)(g0 + sl * WSLOTS), (lptr_t)(d0 + sl * WSLOTS), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gptr_t)(g0 + sl * WSLOTS), (lptr_t)(d0 + sl * WSLOTS), 16, 1024, 0);
             }
     };
     int nsl_cur = 0;

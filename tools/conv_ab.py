@@ -27,6 +27,8 @@ SHAPES = [
     ("up conv1 256>256 @128", 256, 0, 256, 3, 128, 128, 1, 1, 1, 0, 0),
     ("cat conv1 512>256 @64", 256, 256, 256, 3, 64, 64, 1, 1, 0, 0, 0),
     ("conv2 256>256 @64 +skip512", 256, 0, 256, 3, 64, 64, 1, 1, 0, 0, 512),
+    ("conv2 256>256 @64 noskip", 256, 0, 256, 3, 64, 64, 1, 1, 0, 0, 0),
+    ("conv2 128>128 @128 +skip384", 128, 0, 128, 3, 128, 128, 1, 1, 0, 0, 384),
     ("conv 256>256 @32", 256, 0, 256, 3, 32, 32, 1, 1, 0, 0, 0),
     ("cat conv1 384>128 @128", 256, 128, 128, 3, 128, 128, 1, 1, 0, 0, 0),
 ]
