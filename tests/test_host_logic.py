@@ -252,3 +252,102 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "cddpm_oracle" not in src and "import oracle" not in src and "ref_harness" not in src, f
+
+
+# ---- LDS images of the fused convolution (conv_x6.hip): the swizzles are chosen against the bank / lane-group rules of
+#      MI355X_MICROARCH.md (LDS): a ds_read_b128 is served in four groups of 16 lanes over 64 banks of 4 bytes, a
+#      ds_write_b64 in four groups of 16 consecutive lanes over 32 banks. This restates the kernel's slot functions and
+#      checks that every fragment read of every tap, and every patch store, is conflict-free.
+_B128_GROUPS = [[0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27], [4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31]]
+_B128_GROUPS = _B128_GROUPS + [[l + 32 for l in g] for g in _B128_GROUPS]
+
+
+def _read_b128_cycles(addr):          # byte address per lane -> LDS cycles (4 = conflict-free)
+    total = 0
+    for grp in _B128_GROUPS:
+        banks = {}
+        for l in grp:
+            for d in range(4):
+                banks.setdefault((addr[l] // 4 + d) % 64, set()).add(addr[l] // 4 + d)
+        total += max(len(v) for v in banks.values())
+    return total
+
+
+def _write_b64_cycles(addr):          # None = lane masked off
+    total = 0
+    for g in range(4):
+        banks = {}
+        for l in range(16 * g, 16 * g + 16):
+            if addr[l] is None:
+                continue
+            for d in range(2):
+                banks.setdefault((addr[l] // 4 + d) % 32, set()).add(addr[l] // 4 + d)
+        total += max([len(v) for v in banks.values()] + [1])
+    return total
+
+
+def _swz16(pc):
+    return (2 * ((pc >> 1) & 3)) ^ (4 * (pc & 1))
+
+
+def test_conv_lds_images_are_bank_conflict_free():
+    PW = 34
+    # 16x16x32 form, A operand: lane (r = l & 15, g = l >> 4) reads pixel group t16 of wave row pair wm, shifted by (ky, kx)
+    for wm in range(4):
+        for ky in range(3):
+            for kx in range(3):
+                for t16 in range(4):
+                    for sp in range(2):
+                        addr = []
+                        for l in range(64):
+                            r16, g = l & 15, l >> 4
+                            pc = (t16 & 1) * 16 + r16 + kx
+                            pix = (2 * wm + (t16 >> 1) + ky) * PW + pc
+                            addr.append(16 * (pix * 8 + ((4 * sp + g) ^ _swz16(pc))))
+                        assert _read_b128_cycles(addr) == 4, (wm, ky, kx, t16, sp)
+    # ... and the slots of the four pixel groups are constant offsets from the first one (instruction offsets in the kernel)
+    for kx in range(3):
+        for r16 in range(16):
+            for g in range(4):
+                pc0 = r16 + kx
+                base = pc0 * 8 + (g ^ _swz16(pc0))
+                for t16 in range(4):
+                    pc = (t16 & 1) * 16 + r16 + kx
+                    assert ((t16 >> 1) * PW + pc) * 8 + (g ^ _swz16(pc)) == base + ((t16 >> 1) * PW + (t16 & 1) * 16) * 8
+    # weights (host-packed image, both MFMA shapes): slot (4 s + u) ^ ((row >> 1) & 7) of cout row `row`
+    wslot = lambda row, sp, u: row * 8 + ((4 * sp + u) ^ ((row >> 1) & 7))
+    for wn in range(2):
+        for n in range(4):
+            for sp in range(2):
+                addr = [16 * wslot(64 * wn + 16 * n + (l & 15), sp, l >> 4) for l in range(64)]
+                assert _read_b128_cycles(addr) == 4
+                assert all(wslot(64 * wn + 16 * n + r, sp, g) == wslot(64 * wn + r, 0, g) + 128 * n if sp == 0 else True
+                           for r in range(16) for g in range(4))
+        for nt in range(2):
+            for sp in range(2):
+                for jk in range(2):
+                    addr = [16 * wslot(64 * wn + 32 * nt + (l & 31), sp, 2 * jk + (l >> 5)) for l in range(64)]
+                    assert _read_b128_cycles(addr) == 4
+    # 32x32x16 form, A operand: pixel-index swizzle with the parity flip
+    aslot = lambda row, sp, u: row * 8 + ((4 * sp + u) ^ ((row >> 1) & 7) ^ (4 * (row & 1)))
+    for base in range(0, 3 * PW + 3):
+        for sp in range(2):
+            for jk in range(2):
+                addr = [16 * aslot(base + (l & 31), sp, 2 * jk + (l >> 5)) for l in range(64)]
+                assert _read_b128_cycles(addr) == 4
+    # patch stores (8 bytes per lane: thread = (pixel q, channel quad c4)), both swizzles
+    for wave in range(8):
+        for k in range(6):
+            for sp in range(2):
+                a16, a32 = [], []
+                for l in range(64):
+                    tid = wave * 64 + l
+                    c4, q = tid & 7, (tid >> 3) + 64 * k
+                    if q >= 10 * PW:
+                        a16.append(None); a32.append(None)
+                        continue
+                    pc = q % PW
+                    a16.append(16 * (q * 8 + ((4 * sp + (c4 >> 1)) ^ _swz16(pc))) + 8 * (c4 & 1))
+                    a32.append(16 * aslot(q, sp, c4 >> 1) + 8 * (c4 & 1))
+                assert _write_b64_cycles(a16) == 4 and _write_b64_cycles(a32) == 4
+
