@@ -52,6 +52,7 @@ SYMBOLS = {
     "cddpm_p_sample": (_i, [_vp, _fp, _fp, _u64, _u64, _i, _i, _i, _i, _vp]),
     "cddpm_ddim_step": (_i, [_vp, _fp, _fp, _u64, _u64, _i, C.c_float, C.c_float, C.c_float, _i, _i, _i, _i, _i, _vp]),
     "cddpm_noise_fill": (_i, [_vp, _fp, _u64, _u32, _i, _u64, _i, _i, _i, _vp]),
+    "cddpm_residual_postprocess": (_i, [_vp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _fp, _fp, _vp]),
     "cddpm_simplex_fill": (_i, [_vp, _fp, _i64, _i, _i, _i, _i, C.c_double, C.c_double, _vp]),
     "cddpm_q_sample": (_i, [_vp, _fp, _fp, _fp, _i, _fp, _fp, _i, _fp, _i, _i, _i, _vp]),
     "cddpm_set_profiling": (_i, [_vp, _i]),

@@ -11,7 +11,7 @@ import sys
 from concurrent.futures import ThreadPoolExecutor
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-SOURCES = ["conv_mfma.hip", "conv_x6.hip", "conv_pp.hip", "conv_ws.hip", "norm_kernels.hip", "small_kernels.hip", "attention.hip", "simplex.hip", "encoder.hip", "cddpm_api.hip"]
+SOURCES = ["conv_mfma.hip", "conv_x6.hip", "conv_pp.hip", "conv_ws.hip", "norm_kernels.hip", "small_kernels.hip", "attention.hip", "simplex.hip", "encoder.hip", "eval_post.hip", "cddpm_api.hip"]
 LIB = os.path.join(CSRC, "libcddpm_hip.so")
 ARCH = "gfx950"
 

@@ -1056,6 +1056,26 @@ int cddpm_simplex_fill(cddpm_handle h, uint16_t* out_f16_dev, int64_t seed, int 
     return 0;
 }
 
+int cddpm_residual_postprocess(cddpm_handle h, const float* orig_dev, const float* recon_dev, const float* mask_dev,
+                               int S, int H, int W, int squared, int erode_iterations, int median_k, float* tmp_dev,
+                               float* out_dev, void* stream) {
+    if (!h) return -1;
+    if (!orig_dev || !out_dev) return fail(h, "cddpm_residual_postprocess: NULL volume");
+    if (S < 1 || H < 1 || W < 1 || (long long)S * H * W >= (1ll << 31)) return fail(h, "cddpm_residual_postprocess: bad S/H/W");
+    if (erode_iterations < 0) return fail(h, "erode_iterations must be >= 0");
+    if (median_k != 0 && median_k != 3 && median_k != 5) return fail(h, "median_k must be 0, 3 or 5, got %d", median_k);
+    if (median_k && !tmp_dev) return fail(h, "cddpm_residual_postprocess: tmp_dev is NULL but median_k != 0");
+    if (out_dev == orig_dev || out_dev == recon_dev || out_dev == mask_dev || (median_k && tmp_dev == out_dev))
+        return fail(h, "cddpm_residual_postprocess: out_dev aliases an input");
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHECK(h, hipSetDevice(h->device));
+    launch_residual_mask(orig_dev, recon_dev, mask_dev, median_k ? tmp_dev : out_dev, S, H, W, squared ? 1 : 0,
+                         erode_iterations, s);
+    if (median_k) launch_median3d(tmp_dev, out_dev, S, H, W, median_k, s);
+    HIPCHECK(h, hipGetLastError());
+    return 0;
+}
+
 int cddpm_q_sample(cddpm_handle h, const float* x01_dev, const float* noise_dev, const int32_t* t_dev, int t_uniform,
                    const float* sqrt_ac_host, const float* sqrt_1mac_host, int T, float* out_dev, int B, int H, int W,
                    void* stream) {

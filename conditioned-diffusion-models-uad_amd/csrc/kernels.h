@@ -139,4 +139,9 @@ void launch_simplex(unsigned short* out, long long seed, int B, int H, int W, in
 // ------------------------------------------------------------------------------------------------
 void launch_attention(const float* qkv, float* out, int B, int N, int C, hipStream_t stream);
 
+// residual-map post-processing (eval_post.hip; src/utils/utils_eval.py:29-33, :447-464)
+void launch_residual_mask(const float* orig, const float* recon, const float* mask, float* out, int S, int H, int W,
+                          int squared, int iters, hipStream_t stream);
+void launch_median3d(const float* in, float* out, int S, int H, int W, int k, hipStream_t stream);
+
 }  // namespace cddpm

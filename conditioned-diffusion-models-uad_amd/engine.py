@@ -234,6 +234,32 @@ class CddpmEngine:
                                            _stream_ptr(self.device)), "cddpm_noise_fill")
         return out
 
+    def residual_postprocess(self, orig: torch.Tensor, recon: Optional[torch.Tensor], mask: Optional[torch.Tensor] = None, *,
+                             squared: bool = False, erode_iterations: int = 0, median_k: int = 0) -> torch.Tensor:
+        """Residual map of a volume [S,H,W] on the device: |orig - recon| (or squared; recon=None: `orig` as it is), times
+        the eroded brain mask, 3-D median filtered -- the CPU/scipy part of the reference's _test_step
+        (utils_eval.py:29-33, :64-71), bit-exact."""
+        orig = _check_dev(orig, "orig", self.device)
+        if recon is not None:
+            recon = _check_dev(recon, "recon", self.device)
+        if orig.dim() != 3 or (recon is not None and recon.shape != orig.shape):
+            raise RuntimeError("orig / recon must be [S,H,W] volumes of the same shape")
+        mptr = None
+        if mask is not None:
+            mask = _check_dev(mask, "mask", self.device)
+            if mask.shape != orig.shape:
+                raise RuntimeError("mask must have the shape of the volume")
+            mptr = mask.data_ptr()
+        S, H, W = orig.shape
+        out = torch.empty_like(orig)
+        tmp = torch.empty_like(orig) if median_k else None
+        self._ck(self.lib.cddpm_residual_postprocess(self._h, orig.data_ptr(), recon.data_ptr() if recon is not None else None,
+                                                     mptr, S, H, W, int(squared),
+                                                     int(erode_iterations), int(median_k),
+                                                     tmp.data_ptr() if tmp is not None else None, out.data_ptr(),
+                                                     _stream_ptr(self.device)), "cddpm_residual_postprocess")
+        return out
+
     def simplex_noise(self, B: int, H: int, W: int, *, seed: int, octaves: int = 6, persistence: float = 0.8,
                       frequency: float = 64.0) -> torch.Tensor:
         """gen_noise for noisetype 'simplex': float16 [B,1,H,W], the same field for every batch item, bit-exact

@@ -132,6 +132,22 @@ int cddpm_noise_fill(cddpm_handle h, float* out_dev, uint64_t seed, uint32_t str
 int cddpm_simplex_fill(cddpm_handle h, uint16_t* out_f16_dev, int64_t seed, int B, int H, int W, int octaves,
                        double persistence, double frequency, void* stream);
 
+/* Replaces the residual-map post-processing of _test_step (src/utils/utils_eval.py:29-33 residual, :64-66 +
+ * apply_brainmask_volume :447-460, :69-71 + apply_3d_median_filter :462-464), which the reference runs in scipy on the CPU
+ * after copying the volume to the host. Volumes are [S][H][W] fp32 on the device (the reference indexes [H][W][S]; the
+ * filters are symmetric under that permutation):
+ *   out = |orig - recon| (squared = 0) or (orig - recon)^2 (squared = 1); recon_dev == NULL: out = orig (the volume
+ *     already is a residual: apply_brainmask_volume / apply_3d_median_filter on their own);
+ *   mask_dev != NULL: out *= erosion of (mask > 0), per slice, by the 4-connected cross applied erode_iterations times
+ *     (scipy.ndimage.binary_erosion(structure = generate_binary_structure(2, 1), border_value = 0); the reference passes
+ *     iterations = W / 25); erode_iterations = 0 multiplies by the mask as it is;
+ *   median_k = 3 or 5: out = scipy.ndimage.median_filter(out, (k, k, k)), boundary mode 'reflect'; 0 = no filter.
+ * Exact: the results equal scipy's bit for bit (a selection and a product with 0/1). tmp_dev: [S][H][W] scratch, needed
+ * only when median_k != 0 (may be NULL otherwise); out_dev must not alias orig/recon/mask. */
+int cddpm_residual_postprocess(cddpm_handle h, const float* orig_dev, const float* recon_dev, const float* mask_dev,
+                               int S, int H, int W, int squared, int erode_iterations, int median_k, float* tmp_dev,
+                               float* out_dev, void* stream);
+
 /* Replaces q_sample (src/models/modules/cond_DDPM.py:548-554) fused with normalize_to_neg_one_to_one (:75):
  * out = sqrt_ac[t_b] * (2 x01 - 1) + sqrt_1mac[t_b] * noise; coefficient tables are host arrays [T]
  * uploaded on first use. Used by the single-step reconstruction (GaussianDiffusion.forward, :647-655). */
