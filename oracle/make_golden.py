@@ -31,6 +31,10 @@ GOLD = os.path.join(ROOT, "tests", "golden")
 SEED_W, SEED_COND, SEED_XT, SEED_Z = 0, 1, 2, 3   # weights 0, cond 1, x_T 2, z 3
 
 
+# BASELINE config 3 geometry: 256x256 slices (attention over 4096 tokens), the last 12 steps of a T = 1000 chain
+CFG3 = ("loop_cfg3_B1_256x256_T1000_start12", dict(H=256, W=256, B=1, timesteps=1000, start_t=12))
+
+
 def loop_case(sd, H, W, B, timesteps, start_t, slice0=0):
     """reference p_sample_loop with injected draws; returns (reference output, oracle max|diff|)."""
     _model, diff = R.build_reference(sd, image_size=(H, W), timesteps=timesteps)
@@ -49,7 +53,23 @@ def loop_case(sd, H, W, B, timesteps, start_t, slice0=0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--quick", action="store_true")
+    ap.add_argument("--only-cfg3", action="store_true",
+                    help="only the 256x256 loop (BASELINE config 3 geometry); merges its entry into MANIFEST.json")
     args = ap.parse_args()
+    if args.only_cfg3:
+        sd = O.to_torch_sd(synth.synth_state_dict(SEED_W))
+        name, kw = CFG3
+        t0 = time.time()
+        ref, err = loop_case(sd, **kw)
+        np.savez_compressed(os.path.join(GOLD, name + ".npz"), out=ref)
+        with open(os.path.join(GOLD, "MANIFEST.json")) as f:
+            manifest = json.load(f)
+        manifest["cases"][name] = dict(kw, oracle_vs_reference_maxabs=err, seconds=round(time.time() - t0, 1),
+                                       seeds=dict(weights=SEED_W, cond=SEED_COND, xT=SEED_XT, z=SEED_Z))
+        with open(os.path.join(GOLD, "MANIFEST.json"), "w") as f:
+            json.dump(manifest, f, indent=1, sort_keys=True)
+        print(name, "oracle-vs-ref", err, f"{time.time() - t0:.1f}s", flush=True)
+        return
     os.makedirs(GOLD, exist_ok=True)
     torch.manual_seed(0)
     manifest = {"torch": torch.__version__, "threads": torch.get_num_threads(), "cases": {}}
@@ -112,7 +132,7 @@ def main():
              ("loop_B3_32x48_T1000_start5_slice7", dict(H=32, W=48, B=3, timesteps=1000, start_t=5, slice0=7))]
     if not args.quick:
         loops += [("loop_cfg1_B4_128x128_T50_start0", dict(H=128, W=128, B=4, timesteps=50, start_t=0)),
-                  ("loop_B1_128x128_T1000_start50", dict(H=128, W=128, B=1, timesteps=1000, start_t=50))]
+                  ("loop_B1_128x128_T1000_start50", dict(H=128, W=128, B=1, timesteps=1000, start_t=50)), CFG3]
     for name, kw in loops:
         t0 = time.time()
         ref, err = loop_case(sd, **kw)

@@ -193,6 +193,22 @@ def test_unet_forward_256_config3(engine_factory, synth, oracle, sd_torch):
     eng.close()
 
 
+def test_reverse_loop_256_config3_golden(engine_factory, synth):
+    """BASELINE config 3 geometry against the reference's own output: 256x256, the last 12 steps of a T = 1000 chain."""
+    eng = engine_factory(timesteps=1000, max_batch=1, max_h=256, max_w=256)
+    B, H, W, steps = 1, 256, 256, 12
+    x, cond = inputs(synth, B, H, W)
+    noise = np.zeros((steps, B, 1, H, W), np.float32)
+    for t in range(1, steps):
+        noise[t] = synth.noise_z(3, t, 0, B, H, W)
+    out = eng.reverse(x.cuda(), cond.cuda(), steps, noise=torch.from_numpy(noise).cuda()).cpu().numpy()
+    ref = golden("loop_cfg3_B1_256x256_T1000_start12")["out"]
+    err = float(np.abs(out - ref).max())
+    print("256x256 reverse loop max|delta| vs reference:", err)
+    assert err < TOL
+    eng.close()
+
+
 def test_config4_sharded_residual_maps_single_rank(eng1000, synth):
     """BASELINE config 4 in miniature on one rank: slices walked in chunks, residual maps |x - reco| gathered;
     identical to reconstructing every slice in one batch (noise keyed by global slice index)."""

@@ -74,7 +74,8 @@ def test_unet_forward(oracle, synth, sd_torch, B, H, W):
 LOOPS = [("loop_B2_32x32_T1000_start8", 1000, 8, 2, 32, 32, 0),
          ("loop_B2_32x32_T50_start0", 50, 0, 2, 32, 32, 0),
          ("loop_B3_32x48_T1000_start5_slice7", 1000, 5, 3, 32, 48, 7),
-         ("loop_B1_128x128_T1000_start50", 1000, 50, 1, 128, 128, 0)]
+         ("loop_B1_128x128_T1000_start50", 1000, 50, 1, 128, 128, 0),
+         ("loop_cfg3_B1_256x256_T1000_start12", 1000, 12, 1, 256, 256, 0)]     # BASELINE config 3 geometry, ~40 s
 if os.environ.get("CDDPM_SLOW"):
     LOOPS.append(("loop_cfg1_B4_128x128_T50_start0", 50, 0, 4, 128, 128, 0))   # ~4 min on 8 cores
     LOOPS.append(("loop_B2_32x32_T1000_start0", 1000, 0, 2, 32, 32, 0))        # ~3 min: the full T = 1000 chain
