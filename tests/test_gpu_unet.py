@@ -163,6 +163,21 @@ def test_sharding_invariance(eng1000, synth):
     assert torch.equal(full[:2], lo) and torch.equal(full[2:], hi)
 
 
+def test_full_batch_is_the_concatenation_of_small_batches(engine_factory, eng1000, synth):
+    """BASELINE config 2's size (64 slices of 128x128 on one GPU) through a size-independent property: every slice of
+    the B = 64 run equals, bit for bit, the same slice reconstructed in a batch of 4 (golden-pinned geometry), and the
+    first four also match the reference-pinned oracle path indirectly through test_reverse_loop_golden."""
+    eng = engine_factory(timesteps=1000, max_batch=64, max_h=128, max_w=128)
+    H = W = 128
+    x, cond = inputs(synth, 64, H, W)
+    full = eng.reverse(x.cuda(), cond.cuda(), 3, seed=11, slice0=0)
+    assert bool(torch.isfinite(full).all()) and float(full.std()) > 0.01
+    for s0 in (0, 28, 60):
+        part = eng1000.reverse(x[s0:s0 + 4].cuda(), cond[s0:s0 + 4].cuda(), 3, seed=11, slice0=s0)
+        assert torch.equal(full[s0:s0 + 4], part), s0
+    eng.close()
+
+
 def test_errors_are_loud(eng1000, synth):
     x, cond = inputs(synth, 2, 32, 32)
     with pytest.raises(RuntimeError):
