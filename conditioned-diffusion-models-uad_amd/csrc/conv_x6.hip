@@ -128,6 +128,12 @@ __global__ __launch_bounds__(64 * ROWS) void conv_split_kernel(const ConvArgs a)
 #ifndef CDDPM_GLDS
 #define CDDPM_GLDS 1
 #endif
+// timing-only ablations (tools/conv_ab.py; results are WRONG with either): no workgroup barriers in the main loop / no fold
+#ifdef CDDPM_ABL_NOBARRIER
+#define LOOP_BARRIER() __builtin_amdgcn_wave_barrier()
+#else
+#define LOOP_BARRIER() __syncthreads()
+#endif
     constexpr int FOLD = (TAPS == 9) ? CDDPM_X6_FOLD : (TAPS == 4 ? 2 : 1);   // taps per accumulation group
     constexpr int WSLOTS = 128 * SP;                    // 16-B slots of a weight slab
     // taps per weight stage: the fp16 form stages a whole row of taps (3 of the 3x3, 2 of the folded 2x2) per workgroup
@@ -527,9 +533,9 @@ __global__ __launch_bounds__(64 * ROWS) void conv_split_kernel(const ConvArgs a)
         const bool main_seg = chunk < nch_main;
         const int nst = main_seg ? TAPS / TPS : 1;       // stages of this chunk
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this chunk's first weight stage (and its patch registers) have landed
-        __syncthreads();   // ... in every wave, and every wave is done reading the previous patch
+        LOOP_BARRIER();   // ... in every wave, and every wave is done reading the previous patch
         store_act(chunk);
-        __syncthreads();
+        LOOP_BARRIER();
         STAMP(1)
         for (int st = 0; st < nst; ++st) {
             const int ntaps = nsl_cur;                    // taps of this stage
@@ -552,12 +558,14 @@ __global__ __launch_bounds__(64 * ROWS) void conv_split_kernel(const ConvArgs a)
             nsl_cur = nsl_next;
             STAMP(3)
             if (((st + 1) * TPS) % FOLD == 0 || last_st) {
+#ifndef CDDPM_ABL_NOFOLD
                 fold_acc();
+#endif
                 STAMP(4)
             }
             if (!last_st) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();   // the next stage has landed in every wave; this stage's buffer is free
+                LOOP_BARRIER();   // the next stage has landed in every wave; this stage's buffer is free
             }
         }
     }
