@@ -39,7 +39,8 @@ def _worker(rank, world, port, n_slices, chunk, mode, q):
         return _fake_reco(s0, cnt)
 
     out = sh.reconstruct_sharded(n_slices, (8, 12), run, chunk=chunk, gather=mode)
-    q.put((rank, calls, None if out is None else out.clone()))
+    # by value (numpy -> pickle), not as a shared-memory tensor: the worker may exit before the parent has mapped it
+    q.put((rank, calls, None if out is None else out.numpy().copy()))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -54,8 +55,8 @@ def test_two_rank_shard_and_gather(n_slices, chunk, mode):
         p.start()
     res = {}
     for _ in range(world):
-        r, calls, out = q.get(timeout=120)
-        res[r] = (calls, out)
+        r, calls, out = q.get(timeout=300)
+        res[r] = (calls, None if out is None else torch.from_numpy(out))
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
