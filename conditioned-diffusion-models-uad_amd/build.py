@@ -11,8 +11,9 @@ import sys
 from concurrent.futures import ThreadPoolExecutor
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-SOURCES = ["conv_mfma.hip", "conv_x6.hip", "conv_pp.hip", "conv_ws.hip", "norm_kernels.hip", "small_kernels.hip", "attention.hip", "simplex.hip", "encoder.hip", "eval_post.hip", "cddpm_api.hip"]
+SOURCES = ["conv_mfma.hip", "conv_x6.hip", "norm_kernels.hip", "small_kernels.hip", "attention.hip", "simplex.hip", "encoder.hip", "eval_post.hip", "cddpm_api.hip"]
 LIB = os.path.join(CSRC, "libcddpm_hip.so")
+OBJ = os.path.join(CSRC, "_obj")      # object files: git-ignored and .gpurunignore-d (only the .so travels to the GPU box)
 ARCH = "gfx950"
 
 
@@ -39,11 +40,12 @@ def build_lib(force: bool = False, verbose: bool = False, defines=(), tag: str =
     if not force and not tag and lib_is_current():
         return LIB
     hipcc = _hipcc()
+    os.makedirs(OBJ, exist_ok=True)
     flags = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"] + [f"-D{d}" for d in defines]
     objs = []
 
     def compile_one(src):
-        obj = os.path.join(CSRC, src.replace(".hip", f"{('_' + tag) if tag else ''}.o"))
+        obj = os.path.join(OBJ, src.replace(".hip", f"{('_' + tag) if tag else ''}.o"))
         # A/B of older conv kernels: an alternative file replaces conv_x6.hip if its name starts with conv_x6, else conv_mfma.hip
         swap = "conv_x6.hip" if os.path.basename(conv_src).startswith("conv_x6") else "conv_mfma.hip"
         path = conv_src if (conv_src and src == swap) else os.path.join(CSRC, src)

@@ -102,6 +102,7 @@ struct cddpm_ctx {
     // stand-alone sweep): buffer -> records storage, and how many records are valid in the current forward
     std::map<const float*, float*> stat_buf;
     std::map<const float*, int> stat_n;
+    std::map<const float*, size_t> stat_cap;       // capacity of each records buffer in floats (checked before every producer launch)
     float *scratch0 = nullptr, *scratch1 = nullptr;   // [max(T,Bmax)][half] for the embedding MLPs
     int max_nsplit = 0;
 
@@ -175,14 +176,23 @@ double conv_bytes(const ConvArgs& a) {
     b += (double)a.Cout * ((double)(a.C0 + a.C1) * a.taps + a.S0 + a.S1);
     return 4.0 * b;
 }
-void conv_launch(cddpm_ctx* h, ConvArgs a, hipStream_t s) {
+int conv_launch(cddpm_ctx* h, ConvArgs a, hipStream_t s) {
     auto it = h->stat_buf.find(a.out);       // outputs that can feed a GroupNorm get their statistics for free
     a.stats = (it != h->stat_buf.end()) ? it->second : nullptr;
+    const int nrec = (a.taps == 4) ? conv_stat_records_up2(a.H, a.W) : conv_stat_records(a.H, a.W);
+    if (a.stats) {
+        // a statically sized buffer against a shape-derived count: refuse to launch rather than write past the end
+        const size_t need = (size_t)a.B * nrec * a.Cout * 2;
+        if (need > h->stat_cap.at(a.out))
+            return fail(h, "GroupNorm statistics records of a %dx%dx%d conv output (B=%d, %d records) need %zu floats, the buffer holds %zu",
+                        a.H, a.W, a.Cout, a.B, nrec, need, h->stat_cap.at(a.out));
+    }
     {
         Prof p(h, a.taps == 1 ? PC_CONV1 : PC_CONV3, conv_flops(a), conv_bytes(a), s);   // taps 4 = folded upsample + 3x3
         launch_conv(a, s);
     }
-    if (a.stats) h->stat_n[a.out] = (a.taps == 4) ? conv_stat_records_up2(a.H, a.W) : conv_stat_records(a.H, a.W);
+    if (a.stats) h->stat_n[a.out] = nrec;
+    return 0;
 }
 
 #define HIPCHECK(h, call)                                                                      \
@@ -353,6 +363,20 @@ void build_program(cddpm_ctx* h) {
     h->taps.assign(h->blocks.size(), nullptr);
 }
 
+// Shape limits of the kernels, checked on the built program (a descriptor can pass validate_desc and still concatenate
+// more channels than a kernel's LDS arrays hold): a GroupNorm / convolution input of C0 + C1 channels needs
+// 3 (C0 + C1) floats of coefficient cache beside the conv's patch and weight stages in 160 KB of LDS, and
+// gn_finalize_kernel keeps one fp64 (sum, sum of squares) pair per concatenated channel in LDS.
+constexpr int MAX_CONCAT_CHANNELS = 1536;
+int check_program(cddpm_ctx* h, cddpm_ctx* err_to) {
+    for (const ResW& r : h->res)
+        if (r.Cin > MAX_CONCAT_CHANNELS)
+            return fail(err_to, "ResBlock %s reads %d concatenated channels; this library supports at most %d "
+                        "(model_channels x channel_mult too wide for the fused GroupNorm/convolution kernels)",
+                        r.prefix.c_str(), r.Cin, MAX_CONCAT_CHANNELS);
+    return 0;
+}
+
 size_t plan_workspace(cddpm_ctx* h, bool do_alloc, int* rc) {
     // returns the byte count; allocates when do_alloc
     const cddpm_unet_desc& d = h->d;
@@ -422,7 +446,7 @@ size_t plan_workspace(cddpm_ctx* h, bool do_alloc, int* rc) {
                 const BlockInfo& bi = h->blocks[op.block];
                 float* sp = nullptr;
                 want(&sp, B * (size_t)nrec_at(bi.ds) * bi.C * 2);
-                if (do_alloc) h->stat_buf[h->hs[pi]] = sp;
+                if (do_alloc) { h->stat_buf[h->hs[pi]] = sp; h->stat_cap[h->hs[pi]] = B * (size_t)nrec_at(bi.ds) * bi.C * 2; }
                 ++pi;
             }
         size_t maxrc = 0;
@@ -431,7 +455,7 @@ size_t plan_workspace(cddpm_ctx* h, bool do_alloc, int* rc) {
         for (int i = 0; i < 3; ++i) {
             float* sp = nullptr;
             want(&sp, B * maxrc * 2);
-            if (do_alloc) h->stat_buf[work[i]] = sp;
+            if (do_alloc) { h->stat_buf[work[i]] = sp; h->stat_cap[work[i]] = B * maxrc * 2; }
         }
     }
     want(&h->coef, 3 * B * maxC);
@@ -488,6 +512,11 @@ const float* stats_of(cddpm_ctx* h, const float* x, int C, int B, int HW, int* n
     float* rec = h->stat_buf.at(x);
     if (it == h->stat_n.end()) {
         const int ns = gn_nsplit(B, HW);
+        if ((size_t)B * ns * C * 2 > h->stat_cap.at(x)) {
+            fail(h, "GroupNorm statistics sweep of a [%d,%d,%d] tensor needs %zu floats, the buffer holds %zu", B, HW, C,
+                 (size_t)B * ns * C * 2, h->stat_cap.at(x));
+            return nullptr;
+        }
         Prof p(h, PC_GN, 0.0, 4.0 * B * (double)HW * C, s);
         launch_gn_partial(x, C, B, HW, ns, rec, s);
         h->stat_n[x] = ns;
@@ -498,23 +527,25 @@ const float* stats_of(cddpm_ctx* h, const float* x, int C, int B, int HW, int* n
     return rec;
 }
 
-void gn_coef(cddpm_ctx* h, const float* x0, int C0, const float* x1, int C1, int B, int HW, const NormW& nw,
-             bool film, int eoff, hipStream_t s) {
+int gn_coef(cddpm_ctx* h, const float* x0, int C0, const float* x1, int C1, int B, int HW, const NormW& nw,
+            bool film, int eoff, hipStream_t s) {
     int n0 = 0, n1 = 0;
     const float* r0 = stats_of(h, x0, C0, B, HW, &n0, s);
     const float* r1 = x1 ? stats_of(h, x1, C1, B, HW, &n1, s) : nullptr;
+    if (!r0 || (x1 && !r1)) return -1;
     Prof p(h, PC_GN, 0.0, 8.0 * B * ((double)n0 * C0 + (double)n1 * C1), s);
     launch_gn_finalize(r0, C0, n0, r1, C1, n1, B, HW, nw.gamma, nw.beta, film ? h->tab : nullptr, h->cpart, h->sumE, eoff,
                        h->d_t, nullptr, h->coef, s);
+    return 0;
 }
 
 void zero_conv_args(ConvArgs& a) { memset(&a, 0, sizeof a); }
 
 // One ResBlock (src/models/modules/OpenAI_Unet.py:284-338): input x0 (+ x1 concatenated), output dst.
-void run_res(cddpm_ctx* h, const ResW& r, const float* x0, int C0, const float* x1, int C1, float* dst, int B, int H,
-             int W, hipStream_t s) {
+int run_res(cddpm_ctx* h, const ResW& r, const float* x0, int C0, const float* x1, int C1, float* dst, int B, int H,
+            int W, hipStream_t s) {
     // H, W: resolution of the block INPUT
-    gn_coef(h, x0, C0, x1, C1, B, H * W, r.gn1, false, 0, s);
+    if (gn_coef(h, x0, C0, x1, C1, B, H * W, r.gn1, false, 0, s)) return -1;
     ConvArgs a;
     zero_conv_args(a);
     a.B = B; a.Cout = r.Cout; a.taps = 9; a.wpk = r.conv1.wpk; a.bias = r.conv1.bias; a.out = h->bufH;
@@ -539,9 +570,9 @@ void run_res(cddpm_ctx* h, const ResW& r, const float* x0, int C0, const float* 
         a.src0 = x0; a.C0 = C0; a.src1 = x1; a.C1 = C1; a.srcH = H; a.srcW = W; a.coef = h->coef; a.silu = 1;
     }
     a.H = Ho; a.W = Wo;
-    conv_launch(h, a, s);
+    if (conv_launch(h, a, s)) return -1;
     // out_layers: GroupNorm * (1 + scale) + shift -> SiLU -> conv, + skip
-    gn_coef(h, h->bufH, r.Cout, nullptr, 0, B, Ho * Wo, r.gn2, true, r.eoff, s);
+    if (gn_coef(h, h->bufH, r.Cout, nullptr, 0, B, Ho * Wo, r.gn2, true, r.eoff, s)) return -1;
     ConvArgs c;
     zero_conv_args(c);
     c.B = B; c.H = Ho; c.W = Wo; c.Cout = r.Cout; c.taps = 9;
@@ -552,19 +583,19 @@ void run_res(cddpm_ctx* h, const ResW& r, const float* x0, int C0, const float* 
     } else {
         c.res = resid; c.res_up = res_up;
     }
-    conv_launch(h, c, s);
+    return conv_launch(h, c, s);
 }
 
 // AttentionBlock (OpenAI_Unet.py:386-394)
-void run_attn(cddpm_ctx* h, const AttnW& w, const float* x, float* dst, int B, int H, int W, hipStream_t s) {
+int run_attn(cddpm_ctx* h, const AttnW& w, const float* x, float* dst, int B, int H, int W, hipStream_t s) {
     const int N = H * W;
-    gn_coef(h, x, w.C, nullptr, 0, B, N, w.norm, false, 0, s);
+    if (gn_coef(h, x, w.C, nullptr, 0, B, N, w.norm, false, 0, s)) return -1;
     ConvArgs a;
     zero_conv_args(a);
     a.B = B; a.H = H; a.W = W; a.Cout = 3 * w.C; a.taps = 1;
     a.src0 = x; a.C0 = w.C; a.srcH = H; a.srcW = W; a.coef = h->coef; a.silu = 0;
     a.wpk = w.qkv.wpk; a.bias = w.qkv.bias; a.out = h->qkvbuf; a.wscale_inv = ldexpf(1.0f, -w.qkv.wexp);
-    conv_launch(h, a, s);
+    if (conv_launch(h, a, s)) return -1;
     {
         Prof pa(h, PC_ATTN, 4.0 * B * (double)N * N * w.C, 4.0 * B * (double)N * 4 * w.C, s);
         launch_attention(h->qkvbuf, h->attbuf, B, N, w.C, s);
@@ -574,7 +605,7 @@ void run_attn(cddpm_ctx* h, const AttnW& w, const float* x, float* dst, int B, i
     p.B = B; p.H = H; p.W = W; p.Cout = w.C; p.taps = 1;
     p.src0 = h->attbuf; p.C0 = w.C; p.srcH = H; p.srcW = W;
     p.wpk = w.proj.wpk; p.bias = w.proj.bias; p.res = x; p.out = dst; p.wscale_inv = ldexpf(1.0f, -w.proj.wexp);
-    conv_launch(h, p, s);
+    return conv_launch(h, p, s);
 }
 
 int check_call(cddpm_ctx* h, int B, int H, int W) {
@@ -624,7 +655,7 @@ int forward_impl(cddpm_ctx* h, const float* x, float* out, int B, int H, int W, 
                     C1 = r.Cin - curC;
                 }
                 if (dst == cur) { dst = pp[ppi]; ppi ^= 1; }
-                run_res(h, r, cur, curC, x1, C1, dst, B, Hc, Wc, s);
+                if (run_res(h, r, cur, curC, x1, C1, dst, B, Hc, Wc, s)) return -1;
                 curC = r.Cout;
                 if (r.down) curds *= 2;
                 if (r.up) curds /= 2;
@@ -632,10 +663,10 @@ int forward_impl(cddpm_ctx* h, const float* x, float* out, int B, int H, int W, 
             }
             case OP_ATTN:
                 if (dst == cur) { dst = pp[ppi]; ppi ^= 1; }
-                run_attn(h, h->attn[op.idx], cur, dst, B, Hc, Wc, s);
+                if (run_attn(h, h->attn[op.idx], cur, dst, B, Hc, Wc, s)) return -1;
                 break;
             case OP_HEAD: {
-                gn_coef(h, cur, curC, nullptr, 0, B, H * W, h->out_norm, false, 0, s);
+                if (gn_coef(h, cur, curC, nullptr, 0, B, H * W, h->out_norm, false, 0, s)) return -1;
                 Prof ph(h, PC_OTHER, 18.0 * B * H * W * curC, 4.0 * B * (double)H * W * (curC + 19), s);
                 launch_head_dots(cur, h->coef, h->head_w9, h->headP, B, H * W, curC, s);
                 launch_head_gather(h->headP, h->head_bias, out, B, H, W, s);
@@ -668,6 +699,7 @@ size_t cddpm_workspace_bytes(const cddpm_unet_desc* desc) {
     if (validate_desc(nullptr, desc)) return 0;
     tmp.d = *desc;
     build_program(&tmp);
+    if (check_program(&tmp, nullptr)) return 0;
     int rc = 0;
     return plan_workspace(&tmp, false, &rc);
 }
@@ -676,6 +708,12 @@ int cddpm_create(cddpm_handle* out, const cddpm_unet_desc* desc, int device) {
     if (!out) return fail(nullptr, "out is NULL");
     *out = nullptr;
     if (validate_desc(nullptr, desc)) return -1;
+    {   // shape limits of the program, before any device is touched (testable without a GPU)
+        cddpm_ctx tmp;
+        tmp.d = *desc;
+        build_program(&tmp);
+        if (check_program(&tmp, nullptr)) return -1;
+    }
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev <= 0) return fail(nullptr, "no HIP device available: %s", hipGetErrorString(e));
@@ -835,12 +873,11 @@ int cddpm_set_schedule(cddpm_handle h, const float* coef1, const float* coef2, c
     if (T != h->d.timesteps) return fail(h, "T=%d does not match the handle's timesteps=%d", T, h->d.timesteps);
     if (objective != CDDPM_PRED_X0 && objective != CDDPM_PRED_NOISE) return fail(h, "unknown objective %d", objective);
     if (!coef1 || !coef2 || !logvar) return fail(h, "coef1/coef2/logvar must not be NULL");
-    if (objective == CDDPM_PRED_NOISE && (!sqrt_recip || !sqrt_recipm1))
-        return fail(h, "pred_noise needs sqrt_recip_alphas_cumprod and sqrt_recipm1_alphas_cumprod");
+    if (!sqrt_recip || !sqrt_recipm1)      // read by pred_noise steps and by every DDIM step (also under pred_x0)
+        return fail(h, "sqrt_recip_alphas_cumprod and sqrt_recipm1_alphas_cumprod must not be NULL");
     HIPCHECK(h, hipSetDevice(h->device));
     const float* src[5] = {coef1, coef2, logvar, sqrt_recip, sqrt_recipm1};
-    for (int i = 0; i < 5; ++i)
-        if (src[i]) HIPCHECK(h, hipMemcpy(h->sched[i], src[i], (size_t)T * sizeof(float), hipMemcpyHostToDevice));
+    for (int i = 0; i < 5; ++i) HIPCHECK(h, hipMemcpy(h->sched[i], src[i], (size_t)T * sizeof(float), hipMemcpyHostToDevice));
     h->objective = objective;
     // time-embedding table: timestep_embedding (util.py:151-171) -> time_embed MLP (OpenAI_Unet.py:598-602)
     // -> time half of every ResBlock's emb_layers (OpenAI_Unet.py:201-207, :300)
@@ -893,7 +930,7 @@ int cddpm_unet_forward(cddpm_handle h, const float* x_dev, const int32_t* t_dev,
     hipStream_t s = (hipStream_t)stream;
     HIPCHECK(h, hipSetDevice(h->device));
     if (t_dev) {
-        HIPCHECK(h, hipMemcpyAsync(h->d_t, t_dev, (size_t)B * sizeof(int), hipMemcpyDeviceToDevice, s));
+        launch_copy_clamp_int(h->d_t, t_dev, B, 0, h->d.timesteps - 1, s);   // per-sample t index device tables: kept inside [0, T)
     } else {
         if (t_uniform < 0 || t_uniform >= h->d.timesteps) return fail(h, "t=%d outside [0, %d)", t_uniform, h->d.timesteps);
         launch_fill_int(h->d_t, B, t_uniform, s);
@@ -1082,12 +1119,16 @@ int cddpm_q_sample(cddpm_handle h, const float* x01_dev, const float* noise_dev,
     if (!h) return -1;
     if (T != h->d.timesteps) return fail(h, "T mismatch");
     if (B < 1 || B > h->d.max_batch || (H * W) % 4) return fail(h, "bad B/H/W");
+    if (!x01_dev || !noise_dev || !out_dev || !sqrt_ac_host || !sqrt_1mac_host) return fail(h, "cddpm_q_sample: NULL argument");
     hipStream_t s = (hipStream_t)stream;
     HIPCHECK(h, hipSetDevice(h->device));
     HIPCHECK(h, hipMemcpyAsync(h->qs_sa, sqrt_ac_host, (size_t)T * sizeof(float), hipMemcpyHostToDevice, s));
     HIPCHECK(h, hipMemcpyAsync(h->qs_s1, sqrt_1mac_host, (size_t)T * sizeof(float), hipMemcpyHostToDevice, s));
-    if (t_dev) HIPCHECK(h, hipMemcpyAsync(h->d_t, t_dev, (size_t)B * sizeof(int), hipMemcpyDeviceToDevice, s));
-    else launch_fill_int(h->d_t, B, t_uniform, s);
+    if (t_dev) launch_copy_clamp_int(h->d_t, t_dev, B, 0, T - 1, s);
+    else {
+        if (t_uniform < 0 || t_uniform >= T) return fail(h, "t=%d outside [0, %d)", t_uniform, T);
+        launch_fill_int(h->d_t, B, t_uniform, s);
+    }
     launch_q_sample(x01_dev, noise_dev, h->d_t, h->qs_sa, h->qs_s1, out_dev, B, H * W, s);
     HIPCHECK(h, hipGetLastError());
     return 0;
@@ -1234,7 +1275,8 @@ int cddpm_op_gn_coef(cddpm_handle h, const float* src0, int C0, const float* src
                      const float* beta_host, const float* film_dev, float* coef_dev, int B, int HW, void* stream) {
     if (!h) return -1;
     const int C = C0 + C1;
-    if (C0 % 4 || C1 % 4 || C % 32 || C > 1024 || C0 > 1024) return fail(h, "cddpm_op_gn_coef: unsupported channels");
+    if (C0 % 4 || C1 % 4 || C % 32 || C > MAX_CONCAT_CHANNELS || C0 > 1024 || C1 > 1024)
+        return fail(h, "cddpm_op_gn_coef: unsupported channels (each source <= 1024, together <= %d)", MAX_CONCAT_CHANNELS);
     hipStream_t s = (hipStream_t)stream;
     HIPCHECK(h, hipSetDevice(h->device));
     const int ns = gn_nsplit(B, HW);
@@ -1256,6 +1298,14 @@ int cddpm_op_gn_coef(cddpm_handle h, const float* src0, int C0, const float* src
     (void)hipFree(g);
     (void)hipFree(bt);
     return 0;
+}
+
+int cddpm_stat_records(int H, int W, int kind) {
+    if (H < 1 || W < 1) return -1;
+    if (kind == 0) return conv_stat_records(H, W);
+    if (kind == 1) return conv_stat_records_up2(H, W);
+    if (kind == 2) return gn_nsplit(1, H * W);
+    return -1;
 }
 
 size_t cddpm_packed_conv_bytes(int Cout, int Cin, int taps) {

@@ -372,8 +372,6 @@ __global__ __launch_bounds__(64 * NWV, NWV / 2) void conv_mfma_kernel(const Conv
 
 void launch_conv(const ConvArgs& a, hipStream_t stream) {
     if (conv_mode() != 0) { launch_conv_split(a, stream); return; }
-    static const bool use_ws = [] { const char* e = getenv("CDDPM_CONV_WS"); return e && e[0] == '1'; }();
-    if (use_ws && a.taps != 4) { launch_conv_ws(a, stream); return; }
     // 4 waves (64 x 64 per wave, 2 waves per SIMD) is the default; CDDPM_CONV_WAVES=8 selects the 8-wave split
     // (64 x 32 per wave, 4 waves per SIMD), which measures the same throughput (tools/conv_ab.py, profiles/)
     static const int nwv = [] { const char* e = getenv("CDDPM_CONV_WAVES"); return (e && e[0] == '8') ? 8 : 4; }();

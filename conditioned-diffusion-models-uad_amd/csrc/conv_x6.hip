@@ -830,7 +830,6 @@ static void launch_split(const ConvArgs& a, hipStream_t stream) {
 }
 
 void launch_conv_split(const ConvArgs& a, hipStream_t stream) {
-    if (conv_mode() == 2 && conv_pp_applicable(a)) { launch_conv_pp(a, stream); return; }
     if (conv_mode() == 1) launch_split<3, 8>(a, stream);
     else launch_split<2, 8>(a, stream);
 }

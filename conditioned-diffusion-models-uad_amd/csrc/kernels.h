@@ -39,18 +39,12 @@ struct ConvArgs {
 inline int conv_stat_records(int H, int W) { return 2 * ((W + 31) / 32) * ((H + 3) / 4); }
 inline int conv_stat_records_up2(int H, int W) { return 8 * ((W / 2 + 31) / 32) * ((H / 2 + 3) / 4); }
 void launch_conv(const ConvArgs& a, hipStream_t stream);
-// wave-specialised persistent variant (conv_ws.hip); launch_conv forwards to it when CDDPM_CONV_WS=1 is set
-void launch_conv_ws(const ConvArgs& a, hipStream_t stream);
 // fp32-accurate variants on the 16-bit matrix pipe (conv_x6.hip): operands split into 16-bit terms whose partial
 // products are exact in fp32. conv_mode(): 2 = fp16 two-term split, three MFMAs per product group (default,
 // CDDPM_CONV=h3 or unset); 1 = bf16 three-term split, six MFMAs (CDDPM_CONV=x6); 0 = the fp32-MFMA kernels of
 // conv_mfma.hip (CDDPM_CONV=f32). Chosen once per process; it also selects the packed weight format.
 int conv_mode();
 void launch_conv_split(const ConvArgs& a, hipStream_t stream);
-// ping-pong schedule of the fp16-split 3x3 convolution without a skip segment (conv_pp.hip): the two waves of a SIMD
-// alternate between MFMA and staging phases; bit-identical results. Experimental (slower so far): opt-in, CDDPM_CONV_PP=1.
-bool conv_pp_applicable(const ConvArgs& a);
-void launch_conv_pp(const ConvArgs& a, hipStream_t stream);
 // mode 2 only (else 0): power-of-two pre-scale exponent of a weight tensor, max|w| * 2^e in [2^13, 2^14)
 int conv_weight_exp(const float* w, size_t n);
 void pack_conv_weights_split(const float* w /*[Cout][Cin][k][k]*/, int Cout, int Cin, int taps, void* dst, int wexp);
@@ -98,6 +92,8 @@ void launch_linear(const float* x, int ldx, const float* W, int ldw, int koff, c
                    int M, int N, int K, int silu_in, hipStream_t stream);
 void launch_fill_int(int* p, int n, int v, hipStream_t stream);
 void launch_add_int(int* p, int n, int v, hipStream_t stream);
+// dst[i] = clamp(src[i], lo, hi): per-sample timesteps handed in by the caller index device tables
+void launch_copy_clamp_int(int* dst, const int* src, int n, int lo, int hi, hipStream_t stream);
 
 // posterior step (cond_DDPM.py:391-444): x <- c1[t] * x0hat + c2[t] * x + exp(0.5 logvar[t]) * z (t > 0)
 struct StepArgs {

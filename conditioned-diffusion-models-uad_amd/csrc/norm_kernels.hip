@@ -76,7 +76,7 @@ __global__ __launch_bounds__(512) void gn_finalize_kernel(const float* __restric
                                                           int sumE, int eoff, const int* __restrict__ t_dev,
                                                           const float* __restrict__ film_direct, float* __restrict__ coef) {
     __shared__ double red[512][5];     // per-thread (s0, q0, s1, q1) of its channel pair; 5: odd stride
-    __shared__ double chS[1024], chQ[1024];
+    __shared__ double chS[1536], chQ[1536];     // one pair per concatenated channel: C0 + C1 <= 1536 (cddpm_api.hip::check_program)
     __shared__ float gm[32], gr[32];
     const int tid = threadIdx.x, b = blockIdx.x;
     const int C = C0 + C1;

@@ -252,6 +252,13 @@ __global__ void add_int_kernel(int* p, int n, int v) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < n) p[i] += v;
 }
+__global__ void copy_clamp_int_kernel(int* dst, const int* src, int n, int lo, int hi) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = min(max(src[i], lo), hi);
+}
+void launch_copy_clamp_int(int* dst, const int* src, int n, int lo, int hi, hipStream_t stream) {
+    hipLaunchKernelGGL(copy_clamp_int_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, dst, src, n, lo, hi);
+}
 void launch_add_int(int* p, int n, int v, hipStream_t stream) {
     hipLaunchKernelGGL(add_int_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, p, n, v);
 }

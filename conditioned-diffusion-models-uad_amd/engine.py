@@ -145,9 +145,7 @@ class CddpmEngine:
             self.prepare_cond(cond, B)
         out = torch.empty_like(x)
         if isinstance(t, torch.Tensor):
-            tt = t.to(self.device, torch.int32).contiguous()
-            if tt.numel() != B:
-                raise RuntimeError("t must have B elements")
+            tt = self._t_tensor(t, B)
             rc = self.lib.cddpm_unet_forward(self._h, x.data_ptr(), tt.data_ptr(), 0, out.data_ptr(), B, H, W,
                                              _stream_ptr(self.device))
         else:
@@ -155,6 +153,16 @@ class CddpmEngine:
                                              _stream_ptr(self.device))
         self._ck(rc, "cddpm_unet_forward")
         return out
+
+    def _t_tensor(self, t: torch.Tensor, B: int) -> torch.Tensor:
+        """per-sample timesteps index the device tables (time-embedding table, schedule buffers): range-checked here
+        like the reference's `extract` would fail on an out-of-range gather (cond_DDPM.py:266-269)"""
+        if t.numel() != B:
+            raise RuntimeError("t must have B elements")
+        lo, hi = int(t.min()), int(t.max())
+        if lo < 0 or hi >= self.timesteps:
+            raise IndexError(f"timestep indices must lie in [0, {self.timesteps}), got [{lo}, {hi}]")
+        return t.to(self.device, torch.int32).contiguous()
 
     def reverse(self, x_T: torch.Tensor, cond: Optional[torch.Tensor], t_start: int, *, noise: Optional[torch.Tensor] = None,
                 seed: int = 0, slice0: int = 0) -> torch.Tensor:
@@ -276,7 +284,7 @@ class CddpmEngine:
         out = torch.empty_like(x01)
         sa, s1 = self._qs
         if isinstance(t, torch.Tensor):
-            tt = t.to(self.device, torch.int32).contiguous()
+            tt = self._t_tensor(t, B)
             tp, tu = tt.data_ptr(), 0
         else:
             tt, tp, tu = None, None, int(t)

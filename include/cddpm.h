@@ -77,7 +77,8 @@ int cddpm_load_weights(cddpm_handle h, const char* const* names, const float* co
 /* Replaces the registered schedule buffers GaussianDiffusion reads in q_posterior / p_sample
  * (src/models/modules/cond_DDPM.py:366-371, :391-398, :444). Host arrays of length T:
  * posterior_mean_coef1, posterior_mean_coef2, posterior_log_variance_clipped,
- * sqrt_recip_alphas_cumprod, sqrt_recipm1_alphas_cumprod (last two only read for CDDPM_PRED_NOISE).
+ * sqrt_recip_alphas_cumprod, sqrt_recipm1_alphas_cumprod (the last two are read by CDDPM_PRED_NOISE steps and by every
+ * DDIM step, cond_DDPM.py:385-389, :491; all five are required).
  * Also (re)builds the per-ResBlock time-embedding tables, so weights must be loaded first. */
 int cddpm_set_schedule(cddpm_handle h, const float* coef1, const float* coef2, const float* logvar,
                        const float* sqrt_recip, const float* sqrt_recipm1, int T, int objective);
@@ -214,6 +215,12 @@ int cddpm_op_gn_coef(cddpm_handle h, const float* src0_dev, int C0, const float*
  * PyTorch-layout w_host [Cout][Cin][k][k] (taps = k*k in {1, 9}) and returns the format, or -1 on a bad shape. */
 size_t cddpm_packed_conv_bytes(int Cout, int Cin, int taps);
 int cddpm_pack_conv_weights(const float* w_host, int Cout, int Cin, int taps, void* dst_host, int* scale_exp_out);
+
+/* GroupNorm statistics record counts per sample for an H x W tensor (host arithmetic, callable without a GPU):
+ * kind 0 = records the fused convolution's epilogue writes, 1 = the folded-upsample convolution's, 2 = the stand-alone
+ * sweep's pixel-range split. cddpm_create sizes every records buffer for the largest of the three at max_h x max_w, and
+ * every producer launch is refused if its count would not fit (tests/test_host_logic.py checks the counts are monotone). */
+int cddpm_stat_records(int H, int W, int kind);
 
 /* standalone attention core on qkv NHWC [B,N,3C] (q | k | v, heads = contiguous groups of head_channels):
  * out [B,N,C] = softmax(q k^T / sqrt(head_channels)) v  (QKVAttention, OpenAI_Unet.py:457-476). */

@@ -1,0 +1,132 @@
+"""ORACLE tooling -- build-container only: the FULL-LENGTH headline chain (BASELINE config 2 geometry).
+
+Runs the REFERENCE `p_sample_loop` (cond_DDPM.py:446-464, imported from /root/reference by ref_harness.py) for all
+T = 1000 steps at 128x128 on B = 2 slices (SURVEY 8d "Config 2": "do it once for B=2 and commit goldens"), then the
+oracle in fp32 (restatement check) and in float64 (the rounding-free yardstick).  Besides the final reconstruction it
+records the reference's intermediate states x_t at a few t (captured from the tensor the reference hands to
+`torch.randn_like` at step t, cond_DDPM.py:440), so a GPU mismatch can be located along the chain.
+
+    python oracle/make_golden_cfg2.py [--stage ref|oracle|fp64|all] [--threads N]     # ~20 + 20 + 50 min on 8 cores
+
+Also regenerates loop_B2_32x32_T1000_start0 with `--small` (the 32x32 full-length chain, ~3 min).
+Outputs only (no inputs, no reference text): tests/golden/<name>.npz, <name>_fp64.npz, and a MANIFEST.json entry.
+"""
+from __future__ import annotations
+
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+synth = importlib.import_module("conditioned-diffusion-models-uad_amd.synth")
+import cddpm_oracle as O  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+SEED_W, SEED_COND, SEED_XT, SEED_Z = 0, 1, 2, 3
+CAPTURE_T = (750, 500, 250, 50)          # x_t as the reference holds it when it ENTERS step t
+
+
+def inputs(B, H, W):
+    cond = torch.from_numpy(synth.synth_cond(SEED_COND, 0, B))
+    xT = torch.from_numpy(synth.noise_xT(SEED_XT, 0, B, H, W))
+    return cond, xT
+
+
+def z_of(B, H, W):
+    return lambda t: torch.from_numpy(synth.noise_z(SEED_Z, t, 0, B, H, W))
+
+
+def run_reference(name, B, H, W, T):
+    import ref_harness as R
+    sd = O.to_torch_sd(synth.synth_state_dict(SEED_W))
+    _m, diff = R.build_reference(sd, image_size=(H, W), timesteps=T)
+    cond, xT = inputs(B, H, W)
+    z = z_of(B, H, W)
+    captured = {}
+    state = {"t": T - 1, "t0": time.time()}
+    orig_randn, orig_like = torch.randn, torch.randn_like
+
+    def randn(*shape, **kw):                     # the one x_T draw (cond_DDPM.py:454)
+        return xT.clone()
+
+    def randn_like(x, **kw):                     # one draw per step t = T-1 .. 1 (cond_DDPM.py:440); x is x_t
+        t = state["t"]
+        if t in CAPTURE_T:
+            captured[f"x_t{t}"] = x.detach().numpy().copy()
+        if t % 50 == 0:
+            print(f"  reference step t={t}  {time.time() - state['t0']:.0f}s", flush=True)
+        state["t"] = t - 1
+        return z(t)
+
+    torch.randn, torch.randn_like = randn, randn_like
+    try:
+        ref = diff.p_sample_loop((B, 1, H, W), cond=cond, start_t=0)
+    finally:
+        torch.randn, torch.randn_like = orig_randn, orig_like
+    assert state["t"] == 0, state              # exactly T-1 randn_like draws, none at t = 0
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), out=ref.numpy(), **captured)
+    return time.time() - state["t0"]
+
+
+def run_oracle(name, B, H, W, T, fp64):
+    sd = O.to_torch_sd(synth.synth_state_dict(SEED_W))
+    buf = O.schedule_buffers(T)
+    cond, xT = inputs(B, H, W)
+    z = z_of(B, H, W)
+    if fp64:
+        sd, buf, cond, xT = O.to_float64(sd), O.to_float64(buf), cond.double(), xT.double()
+        zz = lambda t: z(t).double()            # noqa: E731
+    else:
+        zz = z
+    t0 = time.time()
+    out = O.p_sample_loop(xT, cond, sd, buf, zz, start_t=0)
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    err = float(np.abs(g["out"].astype(np.float64) - out.numpy().astype(np.float64)).max())
+    if fp64:
+        np.savez_compressed(os.path.join(GOLD, name + "_fp64.npz"), out=out.numpy().astype(np.float64),
+                            reference_fp32_vs_fp64_maxabs=np.float64(err))
+    return err, time.time() - t0
+
+
+def manifest_update(name, **kw):
+    path = os.path.join(GOLD, "MANIFEST.json")
+    with open(path) as f:
+        man = json.load(f)
+    man["cases"].setdefault(name, {}).update(kw)
+    with open(path, "w") as f:
+        json.dump(man, f, indent=1, sort_keys=True)
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--stage", default="all", choices=("ref", "oracle", "fp64", "all"))
+    ap.add_argument("--small", action="store_true", help="32x32 instead of 128x128")
+    ap.add_argument("--threads", type=int, default=0)
+    a = ap.parse_args()
+    if a.threads:
+        torch.set_num_threads(a.threads)
+    B, T = 2, 1000
+    H = W = 32 if a.small else 128
+    name = f"loop_B2_32x32_T1000_start0" if a.small else "loop_cfg2_B2_128x128_T1000_start0"
+    base = dict(B=B, H=H, W=W, timesteps=T, start_t=0, captured_t=list(CAPTURE_T),
+                seeds=dict(weights=SEED_W, cond=SEED_COND, xT=SEED_XT, z=SEED_Z))
+    if a.stage in ("ref", "all"):
+        s = run_reference(name, B, H, W, T)
+        manifest_update(name, **base, reference_seconds=round(s, 1), threads=torch.get_num_threads())
+        print(name, f"reference done {s:.0f}s", flush=True)
+    if a.stage in ("oracle", "all"):
+        err, s = run_oracle(name, B, H, W, T, fp64=False)
+        manifest_update(name, oracle_vs_reference_maxabs=err, oracle_seconds=round(s, 1))
+        print(name, "oracle fp32 vs reference:", err, f"{s:.0f}s", flush=True)
+    if a.stage in ("fp64", "all"):
+        err, s = run_oracle(name, B, H, W, T, fp64=True)
+        manifest_update(name, reference_fp32_vs_fp64_maxabs=err, fp64_seconds=round(s, 1))
+        print(name, "reference fp32 vs oracle float64:", err, f"{s:.0f}s", flush=True)

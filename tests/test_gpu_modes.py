@@ -1,7 +1,6 @@
 """GPU: the two alternative convolution families stay parity-green. The family is chosen once per process
 (CDDPM_CONV, csrc/conv_x6.hip::conv_mode), so each one runs the kernel parity tests in a child process:
-x6 = exact three-term bf16 split (six MFMAs per product group), f32 = fp32 MFMA (conv_mfma.hip), pp = the default
-family under the experimental ping-pong schedule (conv_pp.hip, CDDPM_CONV_PP=1).
+x6 = exact three-term bf16 split (six MFMAs per product group), f32 = fp32 MFMA (conv_mfma.hip).
 The default family (two-term fp16 split) is what every other GPU test exercises."""
 import os
 import subprocess
@@ -14,10 +13,9 @@ from conftest import ROOT
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("mode", ["x6", "f32", "pp"])
+@pytest.mark.parametrize("mode", ["x6", "f32"])
 def test_alternative_conv_family(mode):
-    # "pp": the default fp16-split family with the experimental ping-pong schedule of conv_pp.hip
-    env = dict(os.environ, CDDPM_CONV_PP="1") if mode == "pp" else dict(os.environ, CDDPM_CONV=mode)
+    env = dict(os.environ, CDDPM_CONV=mode)
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_kernels.py"), "-m", "gpu", "-x", "-q",
                         "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]

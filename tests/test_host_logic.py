@@ -175,6 +175,55 @@ def test_library_exports_every_declared_symbol():
     assert b"model_channels" in lib.cddpm_last_error(None)
 
 
+def _desc(lib_mod, model_channels=128, mults=(1, 2, 2), max_batch=4, max_h=128, max_w=128):
+    d = lib_mod.UnetDesc()
+    d.in_channels = d.out_channels = 1
+    d.model_channels, d.num_levels, d.num_res_blocks, d.head_channels, d.cond_dim = model_channels, len(mults), 3, 64, 128
+    for i, m in enumerate(mults):
+        d.channel_mult[i] = m
+    d.num_attention_resolutions = 0
+    d.timesteps, d.max_batch, d.max_h, d.max_w = 1000, max_batch, max_h, max_w
+    return d
+
+
+def test_create_refuses_a_concatenation_wider_than_the_kernels_hold():
+    """(128, (1,2,4,8)) -- the mirror's own default dim_mults -- concatenates 1024 + 1024 channels on the output path:
+    more than gn_finalize_kernel's per-channel LDS arrays and the conv's coefficient cache hold. The
+    descriptor must be refused by name, before any device is touched, instead of faulting later."""
+    lib_mod = load_pkg("_lib")
+    lib = lib_mod.load_library()
+    d = _desc(lib_mod, 128, (1, 2, 4, 8), max_h=128, max_w=128)
+    assert lib.cddpm_workspace_bytes(ctypes.byref(d)) == 0
+    assert b"concatenated channels" in lib.cddpm_last_error(None)
+    h = ctypes.c_void_p()
+    assert lib.cddpm_create(ctypes.byref(h), ctypes.byref(d), 0) != 0 and not h.value
+    assert b"concatenated channels" in lib.cddpm_last_error(None)
+    # the widest supported: 384 x (1, 2) concatenates 768 + 768 = 1536 at the deepest level; 512 x (1, 2) would be 2048
+    assert lib.cddpm_workspace_bytes(ctypes.byref(_desc(lib_mod, 384, (1, 2), max_h=64, max_w=64))) > 0
+    assert lib.cddpm_workspace_bytes(ctypes.byref(_desc(lib_mod, 512, (1, 2), max_h=64, max_w=64))) == 0
+    assert lib.cddpm_workspace_bytes(ctypes.byref(_desc(lib_mod, 128, (1, 2, 4), max_h=64, max_w=64))) > 0
+
+
+def test_groupnorm_record_counts_fit_buffers_sized_at_the_maximum_geometry():
+    """The statistics buffers are sized once, at max_h x max_w (cddpm_api.hip::plan_workspace); a call at any smaller
+    H x W (each <= its maximum, multiples of 4) must never need more records -- the class of bug behind the round-1
+    memory fault (a buffer sized for 2 record classes, a kernel writing 8). Every producer launch also checks its count
+    against the capacity at run time (conv_launch / stats_of)."""
+    lib = load_pkg("_lib").load_library()
+    rec = lambda h, w, k: lib.cddpm_stat_records(h, w, k)
+    for Hm, Wm in ((128, 128), (256, 256), (96, 96), (64, 96), (32, 48), (160, 192)):
+        for ds in (1, 2, 4):
+            cap = max(rec(Hm // ds, Wm // ds, k) for k in (0, 1, 2))
+            for h in range(4, Hm + 1, 4):
+                for w in range(4, Wm + 1, 4):
+                    if h % ds or w % ds or h // ds < 1 or w // ds < 1:
+                        continue
+                    hh, ww = h // ds, w // ds
+                    need = max(rec(hh, ww, 0), rec(hh, ww, 2), rec(hh, ww, 1) if (hh % 2 == 0 and ww % 2 == 0) else 0)
+                    assert need <= cap, (Hm, Wm, ds, h, w, need, cap)
+    assert rec(128, 128, 0) == 2 * 4 * 32 and rec(128, 128, 1) == 8 * 2 * 16 and rec(0, 4, 0) == -1
+
+
 def _bf16_rne(x: np.ndarray) -> np.ndarray:
     """float32 -> bf16 (round to nearest even), returned as float32"""
     u = x.astype(np.float32).view(np.uint32).astype(np.uint64)
