@@ -1,28 +1,39 @@
 #!/usr/bin/env python3
 """bench.py -- reconstructed 128x128 slices/sec @ T=1000 of the cDDPM reverse-diffusion path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--size S] [--no-cpu]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--size S] [--no-cpu] [--no-alt] [--no-profile]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json configs[1]): the reference UNet configuration (43.87 M parameters, fp32), a batch of
-64 synthetic single-channel 128x128 slices per GPU, T = 1000. One "step" = one reverse step p_sample
-(UNet forward + posterior update with on-device Philox noise) over the whole batch, executed by
-cddpm_p_sample of libcddpm_hip.so. A slice needs T such steps, every step does identical work, so
-    value [slices/s] = n_gpus * B / (T * seconds_per_step)
-with seconds_per_step from EXACTLY K timed steps (barrier + synchronize on both sides, max over ranks).
-Weights, context vectors and x_T are synthetic (counter RNG, synth.py) and resident in HBM before timing.
+Workload (BASELINE.json configs[1]): the reference UNet configuration (43.87 M parameters, fp32), a batch of 64 synthetic
+single-channel 128x128 slices per GPU, T = 1000: the reference's p_sample_loop (cond_DDPM.py:446-464) executed by
+cddpm_reverse of libcddpm_hip.so, z_t drawn on the device (Philox), x_T / weights / context synthetic (synth.py) and
+resident in HBM before timing.
+
+What a bench "step" is: a SEGMENT of 50 consecutive reverse steps (1/20 of a reconstruction, one cddpm_reverse_range call's
+worth of chain). The timed region executes exactly K of them back to back -- K = 20 (the default, and what the round
+driver passes) is ONE COMPLETE reconstruction x_T -> x_0 in [0,1] of the whole batch: a single cddpm_reverse(t_start =
+1000) call, ~45 s of sustained load, followed (under torchrun) by the path's one collective, the all_gather of the
+reconstructions, inside the timed region. Other K: K*50 reverse steps = floor(K/20) complete reconstructions
+plus the head of the next chain.
+    value [slices/s] = n_gpus * B * (K * 50 / 1000) / seconds        (max over ranks, barrier + synchronize both sides)
+Untimed before it: W segments of warm-up. Untimed after it: a short pass with per-kernel HIP events (roofline), the
+small-batch line, the alternative arithmetic paths and the CPU baseline (rank 0, one GPU only).
 
 Extra objects on the JSON line:
-  roofline      dominant kernel = the fused 3x3 convolution. Default build (conv_x6.hip): fp32 operands split exactly
-                into three bf16 terms, six bf16 MFMAs per product group, fp32 accumulation -- fp32-accurate results
-                on the bf16 matrix pipe. achieved = EXECUTED bf16 FLOPs (6 x the algorithmic fp32 FLOPs of the
-                launches) / their HIP-event durations (events recorded on the launch stream inside the timed
-                steps) against the 2.5 PFLOP/s dense bf16 MFMA peak of MI355X_MICROARCH.md; the fp32-equivalent
-                rate and its ratio to the 157.3 TFLOP/s fp32 MFMA peak are reported beside it.
-                CDDPM_CONV=f32 runs the fp32-MFMA kernels (conv_mfma.hip) and prices against the fp32 peak.
-  cpu_baseline  oracle/cddpm_oracle.py (torch CPU restatement of the reference path, "port") timed on this
-                host's cores on a bounded sample (B=4, a few p_sample steps), rank 0 at N=1 only.
+  roofline      dominant kernel = the fused 3x3 convolution (conv_x6.hip: conv_split_kernel<9,8,2,true> and the
+                folded-upsample form <4,8,2,true>). Default arithmetic: every fp32 operand split into two fp16 terms,
+                three v_mfma_f32_16x16x32_f16 per product group (hi*hi + hi*mid + mid*hi), fp32 accumulation.
+                achieved = EXECUTED 16-bit-pipe FLOPs (3 x the algorithmic fp32 FLOPs of the launches) / their HIP-event
+                durations, events recorded on the launch stream, against the 2.5 PFLOP/s dense fp16 MFMA peak of
+                MI355X_MICROARCH.md; the fp32-equivalent rate is reported beside it.
+  cpu_baseline  oracle/cddpm_oracle.py (torch CPU restatement of the reference path, "port": the reference cannot travel)
+                timed on this host over thread counts {8, 16, 32, all} x B {1, 4}; the fastest is reported with its
+                thread count. A bounded sample: 1 warm-up + 2 timed p_sample steps per point.
+  config.alt_paths   the same workload (10 reverse steps, B = 64) under CDDPM_CONV=f32 (strict fp32 MFMA,
+                v_mfma_f32_32x32x2_f32 -- the arithmetic `north_star` names) and CDDPM_CONV=x6 (exact 3-term bf16 split),
+                each in a child process (the family is chosen once per process).
+  config.small_batch the reference's real call shape (DDPM_2D.py:193: 4 slices per volume): B = 4, 50 reverse steps.
 """
 from __future__ import annotations
 
@@ -30,6 +41,7 @@ import argparse
 import importlib
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -37,51 +49,120 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 PKG = "conditioned-diffusion-models-uad_amd"
 T_TOTAL = 1000
+SEG = 50                           # reverse steps per bench step
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense fp32 MFMA peak (= fp32 vector peak)
-PEAK_BF16_MFMA_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense bf16 / fp16 MFMA peak
+PEAK_16BIT_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 / fp16 MFMA peak
 CONV_MODE = {"f32": "f32", "x6": "x6"}.get(os.environ.get("CDDPM_CONV", ""), "h3")     # mirrors conv_mode() in csrc/conv_x6.hip
 PEAK_HBM_TBPS = 8.0
 FLOP_PER_SLICE_STEP = {128: 265.6e9, 96: 149.1e9, 256: 1075.1e9}     # the reference's operation count
-# executed by this implementation: the two "nearest x2 upsample -> conv3x3" layers (4.83 + 19.33 GMAC @128^2) run as four
-# 2x2-tap convolutions of the low-resolution input = 4/9 of their multiplies
-EXECUTED_FRACTION = 1.0 - (4.832 + 19.328) * (5.0 / 9.0) / 132.79
+# executed by this implementation: the FIRST conv of the two up ResBlocks ("nearest x2 upsample -> conv3x3", 2.416 + 9.664
+# GMAC @128^2, SURVEY 8a block table: half of output_blocks.3.1 / .7.1) runs as four 2x2-tap convolutions of the
+# low-resolution input = 4/9 of its multiplies; their second conv is a plain 3x3
+EXECUTED_FRACTION = 1.0 - (2.416 + 9.664) * (5.0 / 9.0) / 132.79
 BYTES_PER_SLICE_STEP_128 = 1.043e9                                    # SURVEY.md 8(d), fused-kernel model
+DTYPE = {"h3": "f32_emulated_f16x3", "x6": "f32_emulated_bf16x6", "f32": "f32"}[CONV_MODE]
+ARITH = {"h3": "fp32 in, fp32 out, fp32 accumulation; convolution products formed from two-term fp16 splits of both operands "
+               "(|x - hi - mid| <= 2^-23 |x| for |x| >= 2^-2, absolute <= 2^-25 below; weights pre-scaled by a power of two) "
+               "on the fp16 MFMA, 3 of 4 partial products (the dropped mid*mid term <= 2^-22 |ab|); domain |activation| < 65504 "
+               "(beyond it the result is NaN and the engine raises); parity bar 1e-4 vs the fp32 reference holds at full length",
+         "x6": "fp32 in, fp32 out, fp32 accumulation; convolution products formed from exact 3-way bf16 splits of both operands "
+               "on the bf16 MFMA (6 of 9 partial products, the rest < 2^-24 relative); no range limit",
+         "f32": "fp32 MFMA (v_mfma_f32_32x32x2_f32) throughout: exact fp32 products"}[CONV_MODE]
 
 
-def cpu_baseline(synth, size: int, steps: int = 4, batch: int = 4):
+def cpu_baseline(synth, size: int):
     """time the oracle (CPU restatement) on this host: bounded sample, NOT the thing shipped or measured"""
     import torch
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import cddpm_oracle as O
     sd = O.to_torch_sd(synth.synth_state_dict(0))
     buf = O.schedule_buffers(T_TOTAL)
-    x = torch.from_numpy(synth.noise_xT(2, 0, batch, size, size))
-    cond = torch.from_numpy(synth.synth_cond(1, 0, batch))
-    threads = torch.get_num_threads()
-    times = []
-    with torch.no_grad():
-        for i in range(steps + 1):
-            t = T_TOTAL - 1 - i
-            z = torch.from_numpy(synth.noise_z(3, t, 0, batch, size, size))
-            t0 = time.perf_counter()
-            x = O.p_sample(x, t, cond, sd, buf, z)
-            times.append(time.perf_counter() - t0)
-    per_step = sorted(times[1:])[len(times[1:]) // 2]     # median after one warm-up
-    return {"value": batch / (T_TOTAL * per_step), "unit": "slices/s", "cores": threads, "kind": "port",
-            "sample": f"oracle p_sample, B={batch}, {size}x{size}, 1 warm-up + {steps} timed steps (median), "
-                      f"extrapolated x{T_TOTAL} steps; host has {os.cpu_count()} logical CPUs",
-            "s_per_slice_step": per_step / batch}
+    ncpu = os.cpu_count() or 1
+    default_threads = torch.get_num_threads()
+    points, best = [], None
+    t_begin = time.perf_counter()
+    try:
+        for threads in sorted({min(8, ncpu), min(16, ncpu), min(32, ncpu), default_threads}):
+            torch.set_num_threads(threads)
+            for batch in (1, 4):
+                if time.perf_counter() - t_begin > 60.0:          # bounded: never more than about a minute of CPU work
+                    break
+                x = torch.from_numpy(synth.noise_xT(2, 0, batch, size, size))
+                cond = torch.from_numpy(synth.synth_cond(1, 0, batch))
+                times = []
+                with torch.no_grad():
+                    for i in range(3):
+                        t = T_TOTAL - 1 - i
+                        z = torch.from_numpy(synth.noise_z(3, t, 0, batch, size, size))
+                        t0 = time.perf_counter()
+                        x = O.p_sample(x, t, cond, sd, buf, z)
+                        times.append(time.perf_counter() - t0)
+                per_step = min(times[1:])
+                pt = {"threads": threads, "batch": batch, "s_per_slice_step": per_step / batch,
+                      "slices_per_s": batch / (T_TOTAL * per_step)}
+                points.append(pt)
+                if best is None or pt["slices_per_s"] > best["slices_per_s"]:
+                    best = pt
+    finally:
+        torch.set_num_threads(default_threads)
+    return {"value": best["slices_per_s"], "unit": "slices/s", "cores": best["threads"], "kind": "port",
+            "sample": f"oracle p_sample at {size}x{size}, 1 warm-up + 2 timed steps (min) per point, extrapolated x{T_TOTAL} "
+                      f"steps; fastest of threads x batch = {[(p['threads'], p['batch']) for p in points]}: "
+                      f"threads={best['threads']}, B={best['batch']}; host has {ncpu} logical CPUs",
+            "s_per_slice_step": best["s_per_slice_step"], "points": points}
+
+
+def make_engine(torch, dev, B, S):
+    synth = importlib.import_module(PKG + ".synth")
+    sched = importlib.import_module(PKG + ".schedule")
+    eng_mod = importlib.import_module(PKG + ".engine")
+    eng = eng_mod.CddpmEngine(timesteps=T_TOTAL, max_batch=B, max_h=S, max_w=S, device=dev)
+    eng.load_weights(synth.synth_state_dict(0))
+    eng.set_schedule(sched.schedule_buffers(T_TOTAL))
+    return eng, synth
+
+
+def run_chain(eng, synth, x, n_rev, slice0):
+    """n_rev reverse steps on x in place: complete reconstructions from fresh x_T, then the head of the next chain"""
+    done = 0
+    while done < n_rev:
+        n = min(T_TOTAL, n_rev - done)
+        if done:
+            x.copy_(eng.noise_fill(x.shape[0], x.shape[2], x.shape[3], seed=2 + done, stream_id=synth.STREAM_XT, slice0=slice0))
+        eng.reverse_range_(x, T_TOTAL - 1, T_TOTAL - n, seed=3, slice0=slice0)
+        done += n
+    return x
+
+
+def short_rate(torch, dev, B, S, n_rev, warm):
+    """ms per reverse step of a fresh engine at batch B (alt-path children and the small-batch line)"""
+    eng, synth = make_engine(torch, dev, B, S)
+    cond = torch.from_numpy(synth.synth_cond(1, 0, B)).to(dev)
+    x = eng.noise_fill(B, S, S, seed=2, stream_id=synth.STREAM_XT, slice0=0)
+    eng.prepare_cond(cond, B)
+    eng.reverse_range_(x, T_TOTAL - 1, T_TOTAL - warm, seed=3)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    eng.reverse_range_(x, T_TOTAL - 1 - warm, T_TOTAL - warm - n_rev, seed=3)
+    torch.cuda.synchronize(dev)
+    ms = (time.perf_counter() - t0) * 1e3 / n_rev
+    finite = bool(torch.isfinite(x).all().item())
+    eng.close()
+    return {"batch": B, "reverse_steps_timed": n_rev, "ms_per_reverse_step": ms, "slices_per_s": B / (T_TOTAL * ms * 1e-3),
+            "finite": finite}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=20, help="bench steps = segments of 50 reverse steps; 20 = one reconstruction")
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=64, help="slices per GPU (configs[1]: 64)")
     ap.add_argument("--size", type=int, default=128)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--no-profile", action="store_true", help="no per-kernel HIP events in the timed steps")
+    ap.add_argument("--no-alt", action="store_true", help="skip the alternative-arithmetic children and the small-batch line")
+    ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP event pass (no roofline object)")
+    ap.add_argument("--alt-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
     # stdout carries exactly ONE line (the JSON result): anything libraries print there (RCCL's version banner,
@@ -100,125 +181,157 @@ def main():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (the path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    B, S = args.batch, args.size
+
+    if args.alt_child:      # one alternative arithmetic family, chosen by CDDPM_CONV in this child's environment
+        r = short_rate(torch, dev, B, S, n_rev=10, warm=3)
+        r["conv_family"] = CONV_MODE
+        os.write(result_fd, (json.dumps(r) + "\n").encode())
+        return
+
     dist = None
     if world > 1 or "RANK" in os.environ:     # under torchrun the RCCL path is exercised even with one rank
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)   # RCCL
 
-    synth = importlib.import_module(PKG + ".synth")
-    sched = importlib.import_module(PKG + ".schedule")
-    eng_mod = importlib.import_module(PKG + ".engine")
-
-    B, S = args.batch, args.size
     slice0 = rank * B                                   # weak scaling: every rank owns B distinct slices
-    eng = eng_mod.CddpmEngine(timesteps=T_TOTAL, max_batch=B, max_h=S, max_w=S, device=dev)
-    eng.load_weights(synth.synth_state_dict(0))
-    eng.set_schedule(sched.schedule_buffers(T_TOTAL))
+    eng, synth = make_engine(torch, dev, B, S)
     cond = torch.from_numpy(synth.synth_cond(1, slice0, B)).to(dev)
-    x = eng.noise_fill(B, S, S, seed=2, stream_id=synth.STREAM_XT, slice0=slice0)   # x_T on device
     eng.prepare_cond(cond, B)
+    gathered = torch.empty((world * B, 1, S, S), dtype=torch.float32, device=dev) if dist is not None else None
 
-    t = T_TOTAL - 1
-    for _ in range(args.warmup):
-        eng.p_sample_(x, t, seed=3, slice0=slice0)
-        t -= 1
-    eng.set_profiling(not args.no_profile)
+    # ---- warm-up: W segments on a scratch chain (also the first, eager, launch of every kernel)
+    scratch = eng.noise_fill(B, S, S, seed=7, stream_id=synth.STREAM_XT, slice0=slice0)
+    if args.warmup > 0:
+        run_chain(eng, synth, scratch, args.warmup * SEG, slice0)
+    if dist is not None:
+        dist.all_gather_into_tensor(gathered, scratch)          # RCCL warm-up (communicator setup is not part of the metric)
+    x = eng.noise_fill(B, S, S, seed=2, stream_id=synth.STREAM_XT, slice0=slice0)   # x_T on device
+    n_rev = args.steps * SEG
+
+    # ---- timed region: exactly K segments (K = 20: one complete reconstruction) + the path's one collective
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        eng.p_sample_(x, t, seed=3, slice0=slice0)
-        t -= 1
+    run_chain(eng, synth, x, n_rev, slice0)
+    t_gather0 = None
+    if dist is not None:
+        torch.cuda.synchronize(dev)
+        t_gather0 = time.perf_counter()
+        dist.all_gather_into_tensor(gathered, x)                # gather of the per-rank results over xGMI
     torch.cuda.synchronize(dev)
+    t_end_local = time.perf_counter()
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    eng.set_profiling(False)
-    prof = None if args.no_profile else eng.get_profile()
+    gather_ms = (t_end_local - t_gather0) * 1e3 if t_gather0 is not None else 0.0
 
     if dist is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-        # the path's one collective: gather of the per-rank results (here: the current state) over xGMI
-        g0 = time.perf_counter()
-        gathered = torch.empty((world * B, 1, S, S), dtype=torch.float32, device=dev)
-        dist.all_gather_into_tensor(gathered, x)
-        torch.cuda.synchronize(dev)
-        gather_ms = (time.perf_counter() - g0) * 1e3
-    else:
-        gather_ms = 0.0
     finite = bool(torch.isfinite(x).all().item())
+    complete = (n_rev % T_TOTAL == 0)
+    in_range = bool(((x >= 0) & (x <= 1)).all().item()) if complete else None
 
-    s_per_step = elapsed / args.steps
-    value = world * B / (T_TOTAL * s_per_step)
+    value = world * B * (n_rev / T_TOTAL) / elapsed
+    s_per_rev = elapsed / n_rev
     flop_step = FLOP_PER_SLICE_STEP.get(S, 265.6e9 * (S / 128.0) ** 2) * B
+    workload = ("configs[1]" if (S == 128 and B == 64) else ("configs[2] geometry (256x256)" if S == 256 else "non-headline geometry"))
     out = {
         "metric": "reconstructed 128x128 slices/sec @ T=1000" if S == 128 else f"reconstructed {S}x{S} slices/sec @ T=1000",
         "value": value, "unit": "slices/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": s_per_step * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
-        "config": {"workload": ("configs[1]" if (S == 128 and B == 64) else ("configs[2] geometry (256x256)" if S == 256 else "non-headline geometry"))
-                               + f": reference UNet (43.87M params, fp32), {B}x1x{S}x{S} slices per GPU, "
-                               f"T={T_TOTAL}, p_sample steps t={T_TOTAL - 1 - args.warmup}..{t + 1}; value = n_gpus*B/(T*s_per_step)",
-                   "arithmetic": {"h3": "fp32 in, fp32 out, fp32 accumulation; convolution products formed from two-term fp16 splits of both "
-                                        "operands (|x - hi - mid| <= 2^-23 |x|, rms 0.73 x 2^-24; weights pre-scaled by a power of two) on the fp16 MFMA, 3 of 4 "
-                                        "partial products (the 4th < 2^-24 relative); parity bar 1e-4 vs the fp32 reference holds, rounding "
-                                        "noise vs float64 below the reference's own",
-                                  "x6": "fp32 in, fp32 out, fp32 accumulation; convolution products formed from exact 3-way bf16 splits of "
-                                        "both operands on the bf16 MFMA (6 of 9 partial products, the rest < 2^-24 relative)",
-                                  "f32": "fp32 MFMA (v_mfma_f32_32x32x2_f32) throughout"}[CONV_MODE],
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": DTYPE, "data": "synthetic",
+        "config": {"workload": workload + f": reference UNet (43.87M params, fp32 weights), {B}x1x{S}x{S} slices per GPU, T={T_TOTAL}; "
+                               f"one bench step = {SEG} consecutive reverse steps; timed region = {n_rev} reverse steps = "
+                               f"{n_rev / T_TOTAL:g} complete reconstruction(s) x_T -> x_0 by cddpm_reverse"
+                               + (" + all_gather of the results" if dist is not None else ""),
+                   "reverse_steps_per_bench_step": SEG, "reverse_steps_timed": n_rev,
+                   "complete_reconstructions_timed": n_rev / T_TOTAL, "timed_region_s": elapsed,
+                   "ms_per_reverse_step": s_per_rev * 1e3,
+                   "arithmetic": ARITH, "conv_family": CONV_MODE,
                    "batch_per_gpu": B, "global_batch": world * B, "size": S, "T": T_TOTAL,
-                   "parallelism": f"slice-sharded x{world}, no collective in the loop, one all_gather at the end",
-                   "gather_ms": gather_ms, "finite": finite,
-                   "whole_step_tflops": flop_step / s_per_step / 1e12,
-                   "whole_step_frac_of_fp32_peak": flop_step / s_per_step / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                   "parallelism": f"slice-sharded x{world}, no collective in the loop, one all_gather at the end (inside the timed region)",
+                   "gather_ms": gather_ms, "finite": finite, "reconstruction_in_unit_range": in_range,
+                   "whole_step_tflops_fp32_equivalent": flop_step / s_per_rev / 1e12,
                    "whole_step_flops_note": "reference operation count (SURVEY 8d); executed count is x%.4f (folded upsample convs)" % EXECUTED_FRACTION,
-                   "executed_tflops": flop_step * EXECUTED_FRACTION / s_per_step / 1e12,
-                   "hbm_frac_fused_model": (BYTES_PER_SLICE_STEP_128 * (S / 128.0) ** 2 * B + 0.1755e9) / s_per_step / (PEAK_HBM_TBPS * 1e12)},
+                   "executed_tflops_fp32_equivalent": flop_step * EXECUTED_FRACTION / s_per_rev / 1e12,
+                   "hbm_frac_fused_model": (BYTES_PER_SLICE_STEP_128 * (S / 128.0) ** 2 * B + 0.1755e9) / s_per_rev / (PEAK_HBM_TBPS * 1e12)},
     }
-    if prof is not None:
+
+    # ---- per-kernel-class HIP events: a second, short pass outside the timed region
+    if not args.no_profile:
+        nprof = 6
+        eng.set_profiling(True)
+        eng.reverse_range_(scratch, T_TOTAL - 1, T_TOTAL - nprof, seed=3, slice0=slice0)
+        torch.cuda.synchronize(dev)
+        eng.set_profiling(False)
+        prof = eng.get_profile()
         c3 = prof["conv3x3_mfma"]
+        total_ms = sum(v["ms"] for v in prof.values())
         ach = c3["flops"] / (c3["ms"] * 1e-3) / 1e12 if c3["ms"] > 0 else 0.0
-        traffic = None
-        tfile = os.path.join(ROOT, "profiles", "conv3x3_hbm_traffic.json")
+        traffic, traffic_src = None, None
+        tfile = os.path.join(ROOT, "profiles", "r02_conv3x3_hbm_traffic.json")
         if os.path.exists(tfile):
             try:
                 traffic = json.load(open(tfile)).get("bytes_per_launch")
+                traffic_src = "profiles/r02_conv3x3_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, builder run; not measured in this run)"
             except Exception:
                 traffic = None
         if CONV_MODE != "f32":
             nprod = 3.0 if CONV_MODE == "h3" else 6.0
-            kern = ("conv_split_kernel<9,8,%d> and <4,8,%d> (fused GN/FiLM/SiLU + 3x3 conv [+ folded upsample] + skip + GN statistics; "
+            kern = ("conv_split_kernel<9,8,%d> and <4,8,%d> (fused GN/FiLM/SiLU + 3x3 conv [+ folded upsample] + 1x1 skip + GN statistics; "
                     "fp32 operands as %s, %d %s per product group, fp32 accumulate); achieved = executed 16-bit-pipe FLOPs = %d x algorithmic"
                     % ((2, 2, "2 fp16 terms", 3, "v_mfma_f32_16x16x32_f16", 3) if CONV_MODE == "h3"
                        else (3, 3, "3 bf16 terms", 6, "v_mfma_f32_32x32x16_bf16", 6)))
-            roof = {"achieved": nprod * ach, "peak": PEAK_BF16_MFMA_TFLOPS, "frac": nprod * ach / PEAK_BF16_MFMA_TFLOPS,
+            roof = {"achieved": nprod * ach, "peak": PEAK_16BIT_MFMA_TFLOPS, "frac": nprod * ach / PEAK_16BIT_MFMA_TFLOPS,
                     "fp32_equivalent_tflops": ach, "fp32_mfma_peak": PEAK_FP32_MFMA_TFLOPS,
                     "fp32_equivalent_over_fp32_mfma_peak": ach / PEAK_FP32_MFMA_TFLOPS}
         else:
             kern = "conv_mfma_kernel<9,4> and <4,4> (fused GN/FiLM/SiLU + 3x3 conv [+ folded upsample] + skip + GN statistics, fp32 MFMA); FLOPs = executed"
             roof = {"achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "frac": ach / PEAK_FP32_MFMA_TFLOPS}
-        out["roofline"] = {"bound": "mfma", "kernel": kern, **roof, "unit": "TFLOP/s", "traffic": traffic,
+        out["roofline"] = {"bound": "mfma", "kernel": kern, **roof, "unit": "TFLOP/s", "traffic": traffic, "traffic_source": traffic_src,
                            "launches": c3["launches"], "avg_launch_ms": c3["ms"] / max(1, c3["launches"]),
                            "flops_per_launch": c3["flops"] / max(1, c3["launches"]),
                            "algorithmic_bytes_per_launch": c3["bytes"] / max(1, c3["launches"]),
-                           "share_of_step_time": c3["ms"] / (elapsed * 1e3)}
-        out["kernel_classes"] = {k: {"ms_per_step": v["ms"] / args.steps, "launches_per_step": v["launches"] / args.steps,
+                           "share_of_profiled_step_time": c3["ms"] / total_ms if total_ms > 0 else None,
+                           "measured_in": f"{nprof} reverse steps with HIP events on the launch stream, after the timed region"}
+        out["kernel_classes"] = {k: {"ms_per_step": v["ms"] / nprof, "launches_per_step": v["launches"] / nprof,
                                      "tflops": (v["flops"] / (v["ms"] * 1e-3) / 1e12) if v["ms"] > 0 else 0.0,
                                      "algorithmic_GBps": (v["bytes"] / (v["ms"] * 1e-3) / 1e9) if v["ms"] > 0 else 0.0}
                                  for k, v in prof.items()}
+    eng.close()
+    del eng, x, scratch
+    torch.cuda.empty_cache()
+
+    if rank == 0 and world == 1 and not args.no_alt:
+        # the reference's real call shape: 4 slices per volume (DDPM_2D.py:193)
+        out["config"]["small_batch"] = short_rate(torch, dev, 4, S, n_rev=50, warm=10)
+        # the strict-fp32 and exact-bf16-split families on the same workload, one child process each
+        alts = {}
+        for fam in ("f32", "x6"):
+            if fam == CONV_MODE:
+                continue
+            try:
+                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--alt-child", "--batch", str(B), "--size", str(S)],
+                                   env=dict(os.environ, CDDPM_CONV=fam), capture_output=True, text=True, timeout=300)
+                alts[fam] = json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else {"error": r.stderr[-300:]}
+            except Exception as e:      # the headline does not depend on the side measurements
+                alts[fam] = {"error": repr(e)}
+        out["config"]["alt_paths"] = alts
     if rank == 0 and world == 1 and not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(synth, S)
         out["config"]["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
-    eng.close()
     if rank == 0:
         sys.stdout.flush()
         os.write(result_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.destroy_process_group()
+    if not finite or in_range is False:
+        raise SystemExit("bench.py: the reconstruction is not finite / not in [0,1] -- the number above is INVALID")
 
 
 if __name__ == "__main__":

@@ -9,6 +9,8 @@ Added, behind a cfg switch that is absent (= reference behaviour) by default:
                                      (GaussianDiffusion.p_sample_loop) instead of the single-step x0 estimate
     cfg.reverse_start_t: int     ->  start_t of that loop (0 = all `timesteps` steps)
 
+`test_step` follows the reference's evaluation call (:171-286): 4 centre slices, `noise_ensemble` / `step_ensemble`
+averaging, a fresh `gen_noise` (device simplex) field per reconstruction.
 The context encoder is this package's native ResNet-50 (DDPM_encoder.py) unless an
 `encoder=` module is supplied. Out of scope here: training and the scipy post-processing of utils_eval (f4). pytorch_lightning / omegaconf are used when installed and replaced by
 nn.Module / a plain attribute dict when not.
@@ -20,6 +22,7 @@ import torch.nn as nn
 
 from .OpenAI_Unet import UNetModel as OpenAI_UNet
 from .cond_DDPM import GaussianDiffusion
+from .generate_noise import gen_noise
 
 try:  # Lightning 1.5 path first (what the reference pins), then 2.x, then a plain Module
     from pytorch_lightning.core.lightning import LightningModule as _Base  # type: ignore
@@ -114,18 +117,74 @@ class DDPM_2D(_Base):
             t = self.test_timesteps if t is None else t
             return self.diffusion(input, cond=features, t=t - 1, noise=noise)
 
+    def _gen_noise(self, shape, device):
+        """`gen_noise(self.cfg, input.shape).to(self.device)` of the reference (:231, :241): a simplex field drawn on the
+        device (generate_noise.py mirror, bit-exact for a given numpy seed) or None when cfg.noisetype is unset (the
+        diffusion then draws Gaussian noise itself, cond_DDPM.py:577)."""
+        if _cfg_get(self.cfg, "noisetype", None) is None:
+            return None
+        B, _c, H, W = shape
+        return gen_noise(self.cfg, shape, engine=self.diffusion._engine(B, H, W, device))
+
+    @torch.no_grad()
     def test_step(self, batch, batch_idx: int):
-        """vol [1,1,H,W,D] -> slices [D,1,H,W] -> reconstruction [H,W,D] (reference :171-286). The scipy/sklearn
-        post-processing `_test_step` of the reference is called when `src.utils.utils_eval` is importable
-        (i.e. when this class is dropped into the reference tree); otherwise the tensors are returned."""
-        vol = batch["vol"]
-        data = vol["data"] if isinstance(vol, dict) else vol
-        input = data.squeeze(0).permute(3, 0, 1, 2)                      # [D,1,H,W]   (:210)
+        """The evaluation call of the reference (src/models/DDPM_2D.py:171-286), same order of operations:
+        the 4 centre slices of the volume (`num_eval_slices` is hard-wired to 4 at :193; :194-203), depth to the batch
+        axis (:210), context c = encoder(slices) (:214), then either the noise ensemble (`noise_ensemble: True` in the
+        experiment yaml :22: reconstructions at t in `step_ensemble` = [250, 500, 750], each from a FRESH `gen_noise`
+        field, averaged, :225-236) or one reconstruction at `test_timesteps` (:240-247); volume re-assembled as
+        [1,1,H,W,D] (:256-275). cfg.reverse_sampling (absent in the reference) swaps the single-step estimate for the
+        reverse loop at the same call site. The scipy/sklearn post-processing `_test_step` (:277) runs when the reference's
+        `src.utils.utils_eval` is importable (this class dropped into the reference tree) and the batch carries its
+        inputs; the tensors are returned either way."""
+        def data_of(key):
+            v = batch.get(key) if hasattr(batch, "get") else None
+            if v is None:
+                return None
+            return v["data"] if isinstance(v, dict) else v
+
+        input = data_of("vol")                                              # [1,1,H,W,D]
+        data_orig, data_seg, data_mask = data_of("vol_orig"), data_of("seg_orig"), data_of("mask_orig")
+        if data_seg is None and data_orig is not None:
+            data_seg = torch.zeros_like(data_orig)
+        self.cfg["num_eval_slices"] = 4                                      # (:193)
+        D = input.size(4)
+        num_slices = _cfg_get(self.cfg, "num_eval_slices", D)
+        ind_offset = 0
+        if num_slices != D:
+            start_slice = int((D - num_slices) / 2)                          # (:196)
+            sl = slice(start_slice, start_slice + num_slices)
+            input = input[..., sl]
+            data_orig = data_orig[..., sl] if data_orig is not None else None
+            data_seg = data_seg[..., sl] if data_seg is not None else None
+            data_mask = data_mask[..., sl] if data_mask is not None else None
+            ind_offset = start_slice
+        assert input.shape[0] == 1, "Batch size must be 1"
+        input = input.squeeze(0).permute(3, 0, 1, 2).contiguous()           # [D,1,H,W]   (:210)
         features = self(input)
-        noise = torch.randn_like(input)                                  # Gaussian branch of gen_noise
-        loss, reco = self.reconstruct(input, features, noise)
-        final_volume = reco.clone().squeeze().permute(1, 2, 0).unsqueeze(0).unsqueeze(0)   # (:256-262)
-        return {"loss": loss, "final_volume": final_volume, "input": input, "features": features}
+        if _cfg_get(self.cfg, "noise_ensemble", False):
+            timesteps = list(_cfg_get(self.cfg, "step_ensemble", [250, 500, 750]))
+            reco_ensemble = torch.zeros_like(input)
+            for t in timesteps:
+                noise = self._gen_noise(input.shape, input.device)
+                loss_diff, reco = self.reconstruct(input, features, noise, t=t)
+                reco_ensemble += reco
+            reco = reco_ensemble / len(timesteps)
+        else:
+            timesteps = [self.test_timesteps]
+            noise = self._gen_noise(input.shape, input.device)
+            loss_diff, reco = self.reconstruct(input, features, noise, t=self.test_timesteps)
+        final_volume = reco.clone().squeeze().permute(1, 2, 0).unsqueeze(0).unsqueeze(0)   # (:256-275)
+        out = {"loss": loss_diff, "final_volume": final_volume, "input": input, "features": features,
+               "timesteps": timesteps, "ind_offset": ind_offset}
+        if data_orig is not None and data_mask is not None and hasattr(self, "eval_dict"):
+            try:
+                from src.utils.utils_eval import _test_step  # type: ignore  (reference tree on sys.path)
+            except Exception:
+                _test_step = None
+            if _test_step is not None:
+                _test_step(self, final_volume, data_orig, data_seg, data_mask, batch_idx, batch.get("ID"), batch.get("label"))
+        return out
 
     def configure_optimizers(self):
         return torch.optim.Adam(self.parameters(), lr=_cfg_get(self.cfg, "lr", 1e-4))

@@ -49,6 +49,7 @@ SYMBOLS = {
     "cddpm_prepare_cond": (_i, [_vp, _fp, _i, _vp]),
     "cddpm_unet_forward": (_i, [_vp, _fp, _fp, _i, _fp, _i, _i, _i, _vp]),
     "cddpm_reverse": (_i, [_vp, _fp, _fp, _u64, _u64, _i, _i, _i, _i, _vp]),
+    "cddpm_reverse_range": (_i, [_vp, _fp, _fp, _u64, _u64, _i, _i, _i, _i, _i, _vp]),
     "cddpm_p_sample": (_i, [_vp, _fp, _fp, _u64, _u64, _i, _i, _i, _i, _vp]),
     "cddpm_ddim_step": (_i, [_vp, _fp, _fp, _u64, _u64, _i, C.c_float, C.c_float, C.c_float, _i, _i, _i, _i, _i, _vp]),
     "cddpm_noise_fill": (_i, [_vp, _fp, _u64, _u32, _i, _u64, _i, _i, _i, _vp]),
@@ -63,6 +64,8 @@ SYMBOLS = {
     "cddpm_set_tap": (_i, [_vp, _i, _fp]),
     "cddpm_block_shape": (_i, [_vp, _i, _i, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
     "cddpm_op_conv": (_i, [_vp, _fp, _i, _fp, _i, _fp, _i, _i, _fp, _fp, _i, _i, _fp, _i, _fp, _i, _i, _i, _vp]),
+    "cddpm_op_conv_skip": (_i, [_vp, _fp, _i, _fp, _i, _fp, _fp, _i, _fp, _i, _fp, _fp, _i, _i, _i, _vp]),
+    "cddpm_op_conv_gn": (_i, [_vp, _fp, _i, _fp, _fp, _i, _fp, _fp, _fp, _fp, _i, _i, _i, _vp]),
     "cddpm_op_conv_bench": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, C.POINTER(C.c_double),
                                  C.POINTER(_u64)]),
     "cddpm_op_gn_coef": (_i, [_vp, _fp, _i, _fp, _i, _fp, _fp, _fp, _fp, _i, _i, _vp]),

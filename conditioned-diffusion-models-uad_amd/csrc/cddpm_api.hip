@@ -961,10 +961,10 @@ static void drop_step_graph(cddpm_ctx* h) {
     h->sg = cddpm_ctx::StepGraph();
 }
 
-// steps t_hi, t_hi - 1, ..., 0 as replays of one captured step. The caller has run at least one eager step of this
+// steps t_hi, t_hi - 1, ..., t_lo as replays of one captured step (the step maps to [0,1] exactly when its t is 0). The caller has run at least one eager step of this
 // geometry before (one-time function attributes are set outside the capture).
 static int reverse_by_graph(cddpm_ctx* h, float* img, const float* noise_dev, uint64_t seed, uint64_t slice0, int t_hi,
-                            int B, int H, int W, hipStream_t s) {
+                            int t_lo, int B, int H, int W, hipStream_t s) {
     if (!h->gstream) {
         HIPCHECK(h, hipStreamCreateWithFlags(&h->gstream, hipStreamNonBlocking));
         HIPCHECK(h, hipEventCreateWithFlags(&h->gev_in, hipEventDisableTiming));
@@ -998,7 +998,7 @@ static int reverse_by_graph(cddpm_ctx* h, float* img, const float* noise_dev, ui
     HIPCHECK(h, hipEventRecord(h->gev_in, s));
     HIPCHECK(h, hipStreamWaitEvent(h->gstream, h->gev_in, 0));
     launch_fill_int(h->d_t, B, t_hi, h->gstream);
-    for (int t = t_hi; t >= 0; --t) HIPCHECK(h, hipGraphLaunch(g.exec, h->gstream));
+    for (int t = t_hi; t >= t_lo; --t) HIPCHECK(h, hipGraphLaunch(g.exec, h->gstream));
     HIPCHECK(h, hipEventRecord(h->gev_out, h->gstream));
     HIPCHECK(h, hipStreamWaitEvent(s, h->gev_out, 0));
     return 0;
@@ -1046,28 +1046,36 @@ int cddpm_ddim_step(cddpm_handle h, float* img, const float* z_dev, uint64_t see
     return 0;
 }
 
-int cddpm_reverse(cddpm_handle h, float* img, const float* noise_dev, uint64_t seed, uint64_t slice0, int t_start, int B,
-                  int H, int W, void* stream) {
+int cddpm_reverse_range(cddpm_handle h, float* img, const float* noise_dev, uint64_t seed, uint64_t slice0, int t_hi,
+                        int t_lo, int B, int H, int W, void* stream) {
     if (check_call(h, B, H, W)) return -1;
     if (!img) return fail(h, "img_inout_dev is NULL");
-    if (t_start < 1 || t_start > h->d.timesteps) return fail(h, "t_start=%d outside [1, %d]", t_start, h->d.timesteps);
+    if (t_lo < 0 || t_hi < t_lo || t_hi >= h->d.timesteps)
+        return fail(h, "steps t_hi=%d .. t_lo=%d outside 0 <= t_lo <= t_hi < %d", t_hi, t_lo, h->d.timesteps);
     hipStream_t s = (hipStream_t)stream;
     HIPCHECK(h, hipSetDevice(h->device));
     const size_t HW = (size_t)H * W;
-    int t = t_start - 1;
+    int t = t_hi;
     bool tapped = false;
     for (float* p : h->taps) tapped = tapped || (p != nullptr);
     // CDDPM_GRAPH=1: the first step runs eagerly; with four or more to go the rest is replayed from a captured graph of one
     // step (per-launch profiling and block taps need eager launches)
-    const bool by_graph = graph_replay_enabled() && !h->profiling && !tapped && t_start >= 5;
-    for (; t >= 0; --t) {
+    const bool by_graph = graph_replay_enabled() && !h->profiling && !tapped && (t_hi - t_lo + 1) >= 5;
+    for (; t >= t_lo; --t) {
         if (step_once(h, img, noise_dev ? noise_dev + (size_t)t * B * HW : nullptr, seed, slice0, t, t == 0, B, H, W, s))
             return -1;
         if (by_graph) { --t; break; }
     }
-    if (by_graph && t >= 0 && reverse_by_graph(h, img, noise_dev, seed, slice0, t, B, H, W, s)) return -1;
+    if (by_graph && t >= t_lo && reverse_by_graph(h, img, noise_dev, seed, slice0, t, t_lo, B, H, W, s)) return -1;
     HIPCHECK(h, hipGetLastError());
     return 0;
+}
+
+int cddpm_reverse(cddpm_handle h, float* img, const float* noise_dev, uint64_t seed, uint64_t slice0, int t_start, int B,
+                  int H, int W, void* stream) {
+    if (!h) return -1;
+    if (t_start < 1 || t_start > h->d.timesteps) return fail(h, "t_start=%d outside [1, %d]", t_start, h->d.timesteps);
+    return cddpm_reverse_range(h, img, noise_dev, seed, slice0, t_start - 1, 0, B, H, W, stream);
 }
 
 int cddpm_noise_fill(cddpm_handle h, float* out_dev, uint64_t seed, uint32_t stream_id, int t, uint64_t slice0, int B,
@@ -1195,6 +1203,75 @@ int cddpm_op_conv(cddpm_handle h, const float* src0, int C0, const float* src1, 
     HIPCHECK(h, hipStreamSynchronize(s));
     (void)hipFree(dw);
     (void)hipFree(db);
+    return 0;
+}
+
+int cddpm_op_conv_skip(cddpm_handle h, const float* src0, int C0, const float* coef_dev, int silu, const float* w_host,
+                       const float* bias_host, int Cout, const float* skip_dev, int S0, const float* wskip_host,
+                       float* out_dev, int B, int H, int W, void* stream) {
+    if (!h) return -1;
+    if (C0 % 32 || C0 <= 0 || S0 % 32 || S0 <= 0 || Cout % 128 || Cout <= 0)
+        return fail(h, "cddpm_op_conv_skip: unsupported shape (C0 %d, S0 %d, Cout %d)", C0, S0, Cout);
+    if (!src0 || !skip_dev || !w_host || !wskip_host || !bias_host || !out_dev) return fail(h, "cddpm_op_conv_skip: NULL argument");
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHECK(h, hipSetDevice(h->device));
+    // one pre-scale exponent for both tensors, as cddpm_load_weights chooses it
+    const int wexp = std::min(conv_weight_exp(w_host, (size_t)Cout * C0 * 9), conv_weight_exp(wskip_host, (size_t)Cout * S0));
+    std::vector<float> pk(packed_conv_floats(Cout, C0, 9)), pks(packed_conv_floats(Cout, S0, 1));
+    pack_conv_weights(w_host, Cout, C0, 9, pk.data(), wexp);
+    pack_conv_weights(wskip_host, Cout, S0, 1, pks.data(), wexp);
+    float *dw = nullptr, *dws = nullptr, *db = nullptr;
+    HIPCHECK(h, hipMalloc((void**)&dw, pk.size() * sizeof(float)));
+    HIPCHECK(h, hipMalloc((void**)&dws, pks.size() * sizeof(float)));
+    HIPCHECK(h, hipMalloc((void**)&db, (size_t)Cout * sizeof(float)));
+    HIPCHECK(h, hipMemcpy(dw, pk.data(), pk.size() * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHECK(h, hipMemcpy(dws, pks.data(), pks.size() * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHECK(h, hipMemcpy(db, bias_host, (size_t)Cout * sizeof(float), hipMemcpyHostToDevice));
+    ConvArgs a;
+    zero_conv_args(a);
+    a.src0 = src0; a.C0 = C0; a.srcH = H; a.srcW = W; a.coef = coef_dev; a.silu = silu; a.wpk = dw; a.bias = db;
+    a.skip0 = skip_dev; a.S0 = S0; a.skip_wpk = dws;
+    a.wscale_inv = ldexpf(1.0f, -wexp);
+    a.out = out_dev; a.B = B; a.H = H; a.W = W; a.Cout = Cout; a.taps = 9;
+    launch_conv(a, s);
+    HIPCHECK(h, hipGetLastError());
+    HIPCHECK(h, hipStreamSynchronize(s));
+    (void)hipFree(dw); (void)hipFree(dws); (void)hipFree(db);
+    return 0;
+}
+
+int cddpm_op_conv_gn(cddpm_handle h, const float* src0, int C0, const float* w_host, const float* bias_host, int Cout,
+                     const float* gamma_host, const float* beta_host, float* out_dev, float* coef_dev, int B, int H, int W,
+                     void* stream) {
+    if (!h) return -1;
+    if (C0 % 32 || C0 <= 0 || Cout % 128 || Cout <= 0 || Cout > 1024) return fail(h, "cddpm_op_conv_gn: unsupported shape");
+    if (!src0 || !w_host || !bias_host || !gamma_host || !beta_host || !out_dev || !coef_dev) return fail(h, "cddpm_op_conv_gn: NULL argument");
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHECK(h, hipSetDevice(h->device));
+    const int wexp = conv_weight_exp(w_host, (size_t)Cout * C0 * 9);
+    std::vector<float> pk(packed_conv_floats(Cout, C0, 9));
+    pack_conv_weights(w_host, Cout, C0, 9, pk.data(), wexp);
+    const int nrec = conv_stat_records(H, W);
+    float *dw = nullptr, *db = nullptr, *rec = nullptr, *g = nullptr, *bt = nullptr;
+    HIPCHECK(h, hipMalloc((void**)&dw, pk.size() * sizeof(float)));
+    HIPCHECK(h, hipMalloc((void**)&db, (size_t)Cout * sizeof(float)));
+    HIPCHECK(h, hipMalloc((void**)&g, (size_t)Cout * sizeof(float)));
+    HIPCHECK(h, hipMalloc((void**)&bt, (size_t)Cout * sizeof(float)));
+    HIPCHECK(h, hipMalloc((void**)&rec, (size_t)B * nrec * Cout * CDDPM_STAT_FLOATS * sizeof(float)));
+    HIPCHECK(h, hipMemcpy(dw, pk.data(), pk.size() * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHECK(h, hipMemcpy(db, bias_host, (size_t)Cout * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHECK(h, hipMemcpy(g, gamma_host, (size_t)Cout * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHECK(h, hipMemcpy(bt, beta_host, (size_t)Cout * sizeof(float), hipMemcpyHostToDevice));
+    ConvArgs a;
+    zero_conv_args(a);
+    a.src0 = src0; a.C0 = C0; a.srcH = H; a.srcW = W; a.wpk = dw; a.bias = db; a.stats = rec;
+    a.wscale_inv = ldexpf(1.0f, -wexp);
+    a.out = out_dev; a.B = B; a.H = H; a.W = W; a.Cout = Cout; a.taps = 9;
+    launch_conv(a, s);
+    launch_gn_finalize(rec, Cout, nrec, nullptr, 0, 0, B, H * W, g, bt, nullptr, nullptr, 0, 0, nullptr, nullptr, coef_dev, s);
+    HIPCHECK(h, hipGetLastError());
+    HIPCHECK(h, hipStreamSynchronize(s));
+    for (void* p : {(void*)dw, (void*)db, (void*)g, (void*)bt, (void*)rec}) (void)hipFree(p);
     return 0;
 }
 

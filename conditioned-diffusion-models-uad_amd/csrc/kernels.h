@@ -36,6 +36,7 @@ struct ConvArgs {
     float* stats;
     float wscale_inv;    // conv_mode() == 2: 2^-wexp of the packed weights (main and skip segment share it); else unused
 };
+#define CDDPM_STAT_FLOATS 2      // floats per (record, channel): (sum, sum of squares)
 inline int conv_stat_records(int H, int W) { return 2 * ((W + 31) / 32) * ((H + 3) / 4); }
 inline int conv_stat_records_up2(int H, int W) { return 8 * ((W / 2 + 31) / 32) * ((H / 2 + 3) / 4); }
 void launch_conv(const ConvArgs& a, hipStream_t stream);

@@ -184,6 +184,21 @@ class CddpmEngine:
         self._check_finite(x, "cddpm_reverse")
         return x
 
+    def reverse_range_(self, x: torch.Tensor, t_hi: int, t_lo: int, *, noise: Optional[torch.Tensor] = None, seed: int = 0,
+                       slice0: int = 0) -> torch.Tensor:
+        """steps t_hi .. t_lo of the chain IN PLACE on a device tensor (context from the last prepare_cond); the result is
+        mapped to [0,1] exactly when t_lo == 0 (cddpm_reverse_range). No host synchronisation: the caller checks the
+        final reconstruction (`check_finite`)."""
+        x = _check_dev(x, "x", self.device)
+        B, _c, H, W = x.shape
+        nptr = _check_dev(noise, "noise", self.device).data_ptr() if noise is not None else None
+        self._ck(self.lib.cddpm_reverse_range(self._h, x.data_ptr(), nptr, seed, slice0, int(t_hi), int(t_lo), B, H, W,
+                                              _stream_ptr(self.device)), "cddpm_reverse_range")
+        return x
+
+    def check_finite(self, x: torch.Tensor, what: str = "reconstruction"):
+        self._check_finite(x, what)
+
     @staticmethod
     def _check_finite(x: torch.Tensor, what: str):
         """A non-finite reconstruction is an error, not a result. The default convolution family carries fp32 products on
@@ -219,6 +234,7 @@ class CddpmEngine:
 
     def p_sample_(self, x: torch.Tensor, t: int, *, seed: int = 0, slice0: int = 0) -> torch.Tensor:
         """in-place reverse step on a device tensor, context from the last prepare_cond (bench loop)"""
+        x = _check_dev(x, "x", self.device)
         B, _c, H, W = x.shape
         self._ck(self.lib.cddpm_p_sample(self._h, x.data_ptr(), None, seed, slice0, int(t), B, H, W,
                                          _stream_ptr(self.device)), "cddpm_p_sample")
@@ -336,6 +352,31 @@ class CddpmEngine:
             Cout, ksize, res.data_ptr() if res is not None else None, int(res_upsample), out.data_ptr(), B, H, W,
             _stream_ptr(self.device)), "cddpm_op_conv")
         return out
+
+    def op_conv_skip(self, src0, coef, silu, weight, bias, skip, wskip):
+        """conv3x3(act(src0)) + conv1x1(skip) + bias on NHWC device tensors (cddpm_op_conv_skip)"""
+        B, H, W, C0 = src0.shape
+        f = lambda t: np.ascontiguousarray(t.detach().cpu().numpy(), dtype=np.float32)
+        wt, bs, ws = f(weight), f(bias), f(wskip)
+        Cout = wt.shape[0]
+        out = torch.empty((B, H, W, Cout), dtype=torch.float32, device=self.device)
+        self._ck(self.lib.cddpm_op_conv_skip(self._h, src0.data_ptr(), C0, coef.data_ptr() if coef is not None else None, int(silu),
+                                             wt.ctypes.data, bs.ctypes.data, Cout, skip.data_ptr(), skip.shape[-1], ws.ctypes.data,
+                                             out.data_ptr(), B, H, W, _stream_ptr(self.device)), "cddpm_op_conv_skip")
+        return out
+
+    def op_conv_gn(self, src0, weight, bias, gamma, beta):
+        """conv3x3(src0) + bias with the epilogue's GroupNorm statistics -> (out NHWC, coef [3,B,Cout]) (cddpm_op_conv_gn)"""
+        B, H, W, C0 = src0.shape
+        f = lambda t: np.ascontiguousarray(t.detach().cpu().numpy(), dtype=np.float32)
+        wt, bs, g, b = f(weight), f(bias), f(gamma), f(beta)
+        Cout = wt.shape[0]
+        out = torch.empty((B, H, W, Cout), dtype=torch.float32, device=self.device)
+        coef = torch.empty((3, B, Cout), dtype=torch.float32, device=self.device)
+        self._ck(self.lib.cddpm_op_conv_gn(self._h, src0.data_ptr(), C0, wt.ctypes.data, bs.ctypes.data, Cout, g.ctypes.data,
+                                           b.ctypes.data, out.data_ptr(), coef.data_ptr(), B, H, W, _stream_ptr(self.device)),
+                 "cddpm_op_conv_gn")
+        return out, coef
 
     def op_gn_coef(self, src0, src1, gamma, beta, film):
         B = src0.shape[0]

@@ -104,6 +104,13 @@ int cddpm_unet_forward(cddpm_handle h, const float* x_dev, const int32_t* t_dev,
 int cddpm_reverse(cddpm_handle h, float* img_inout_dev, const float* noise_dev, uint64_t seed,
                   uint64_t slice0, int t_start, int B, int H, int W, void* stream);
 
+/* A segment of the same chain: steps t = t_hi, t_hi - 1, ..., t_lo (0 <= t_lo <= t_hi < T) of p_sample_loop's recurrence
+ * (cond_DDPM.py:460-461) on img_inout_dev (values in [-1,1]); the map to [0,1] (:463) is applied exactly when t_lo == 0.
+ * cddpm_reverse(t_start) == cddpm_reverse_range(t_start - 1, 0); cutting a chain into consecutive segments gives
+ * bit-identical results (progress reporting, checkpoints of x_t, bench segments). noise_dev is indexed by the absolute t. */
+int cddpm_reverse_range(cddpm_handle h, float* img_inout_dev, const float* noise_dev, uint64_t seed, uint64_t slice0,
+                        int t_hi, int t_lo, int B, int H, int W, void* stream);
+
 /* Replaces one GaussianDiffusion.p_sample call (src/models/modules/cond_DDPM.py:432-444): img <- x_{t-1} from x_t,
  * still in [-1,1]. z_dev: the step's N(0,1) draw [B,1,H,W], or NULL for the device Philox (ignored at t == 0). */
 int cddpm_p_sample(cddpm_handle h, float* img_inout_dev, const float* z_dev, uint64_t seed, uint64_t slice0,
@@ -187,6 +194,20 @@ int cddpm_op_conv(cddpm_handle h, const float* src0_dev, int C0, const float* sr
                   const float* w_host, const float* bias_host, int Cout, int ksize,
                   const float* res_dev, int res_upsample,
                   float* out_dev, int B, int H, int W, void* stream);
+
+/* the ResBlock output convolution with its fused 1x1 skip_connection (OpenAI_Unet.py:261-268, :338): out = conv3x3(
+ * act(src)) + conv1x1(skip) + bias, the skip operand RAW (un-normalised residual stream), both weight tensors packed
+ * under one pre-scale exponent as cddpm_load_weights does. skip_dev [B,H,W,S0], wskip_host [Cout,S0,1,1]. Kernel tests. */
+int cddpm_op_conv_skip(cddpm_handle h, const float* src0_dev, int C0, const float* coef_dev, int silu,
+                       const float* w_host, const float* bias_host, int Cout, const float* skip_dev, int S0,
+                       const float* wskip_host, float* out_dev, int B, int H, int W, void* stream);
+
+/* a 3x3 convolution whose epilogue writes the GroupNorm statistics records of its output, followed by gn_finalize:
+ * out_dev [B,H,W,Cout] = conv3x3(src) + bias and coef_dev [3][B][Cout] = (mean, a, d) of GroupNorm32(out) with
+ * gamma/beta -- the statistics path every ResBlock uses (records from the producer, never a re-read). Kernel tests. */
+int cddpm_op_conv_gn(cddpm_handle h, const float* src0_dev, int C0, const float* w_host, const float* bias_host, int Cout,
+                     const float* gamma_host, const float* beta_host, float* out_dev, float* coef_dev, int B, int H, int W,
+                     void* stream);
 
 /* micro-benchmark of the fused conv kernel on device-generated N(0,1) data (no result check): average ms per
  * launch over `iters` launches; res_mode 0 none, 1 same resolution, 2 half resolution; skipC = channels of a fused

@@ -58,10 +58,10 @@ def engine_factory(sd_np):
     sched = load_pkg("schedule")
     made = []
 
-    def make(timesteps=1000, max_batch=4, max_h=128, max_w=128, objective="pred_x0"):
+    def make(timesteps=1000, max_batch=4, max_h=128, max_w=128, objective="pred_x0", beta_schedule="cosine"):
         e = eng_mod.CddpmEngine(timesteps=timesteps, max_batch=max_batch, max_h=max_h, max_w=max_w)
         e.load_weights(sd_np)
-        e.set_schedule(sched.schedule_buffers(timesteps), objective)
+        e.set_schedule(sched.schedule_buffers(timesteps, beta_schedule), objective)
         made.append(e)
         return e
 

@@ -143,3 +143,143 @@ def test_attention(eng, N):
     ref2 = torch.einsum("bts,bcs->bct", wgt, v.reshape(B * heads, ch, N)).reshape(B, C, N)
     got2 = eng.op_attention(qkv2.permute(0, 2, 1).contiguous().cuda()).cpu().permute(0, 2, 1)
     close(got2, ref2, 1e-5)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Edges of the arithmetic domain. The default convolution family carries fp32 products on the
+# fp16 matrix pipe: every operand is hi + mid (two fp16 terms), a*b = hi*hi + hi*mid + mid*hi. Error budget per product:
+#   operand representation   <= 2^-23 |x| each while mid is a normal fp16 (|x| >= 2^-2); ABSOLUTE <= 2^-25 below that
+#                               (activations as they are; weights are pre-scaled so that max|w| lands in [2^13, 2^14),
+#                               i.e. their absolute term is 2^-25 * 2^-13 max|w| -- negligible)
+#   dropped mid*mid           <= 2^-22 |ab|
+#   fp32 accumulation         ~ sqrt(K) 2^-24 of the partial sums
+# => |err| <= 2^-20 sum|a||w| + 2^-24 sum|w|  (documented bound, a factor ~4 above the worst case of the model), where
+# the second term is the absolute error of activations below 2^-2. The exact families (CDDPM_CONV=x6 / f32) have no
+# absolute term. Inputs with |activation| >= 65504 are OUTSIDE the domain of the default family: fp16 overflows and the
+# result is non-finite (loud), the exact families stay finite. All references below are float64.
+# ------------------------------------------------------------------------------------------------------------------
+import os
+
+FAMILY = {"f32": "f32", "x6": "x6"}.get(os.environ.get("CDDPM_CONV", ""), "h3")
+
+
+def conv_bound(v64, w64, pad):
+    s1 = F.conv2d(v64.abs(), w64.abs(), None, padding=pad)
+    s2 = F.conv2d(torch.ones_like(v64), w64.abs(), None, padding=pad)
+    rel, ab = 2.0 ** -20, (2.0 ** -24 if FAMILY == "h3" else 0.0)
+    return rel * s1 + ab * s2 + 1e-30
+
+
+def check_conv64(got_nhwc, v, wt, bias, pad, extra=None, extra_bound=None):
+    v64, w64 = v.double(), wt.double()
+    ref = F.conv2d(v64, w64, bias.double(), padding=pad)
+    lim = conv_bound(v64, w64, pad)
+    if extra is not None:
+        ref = ref + extra
+        lim = lim + extra_bound
+    err = (nchw(got_nhwc).double() - ref).abs()
+    ratio = float((err / lim).max())
+    assert ratio <= 1.0, f"max err/bound {ratio:.3f} (max err {float(err.max()):.3e}, max |ref| {float(ref.abs().max()):.3e})"
+    return ratio
+
+
+SCALES = [("act_1e3", 1e3, 1.0), ("act_1e4", 1e4, 1.0), ("act_1e-4", 1e-4, 1.0), ("act_1e-6", 1e-6, 1.0),
+          ("w_1e3", 1.0, 1e3), ("w_1e-5", 1.0, 1e-5)]
+
+
+@pytest.mark.parametrize("name,sa,sw", SCALES, ids=[s[0] for s in SCALES])
+def test_conv_domain_scaled_operands(eng, name, sa, sw):
+    """activations at 10^3..10^4 and at 10^-4..10^-6 (far below the 2^-2 threshold of the relative bound), weights at
+    10^3 / 10^-5 (the pre-scale exponent absorbs them)"""
+    torch.manual_seed(hash(name) % 1000)
+    B, Cin, Cout, H, W = 2, 128, 128, 8, 32
+    x = torch.randn(B, Cin, H, W) * sa
+    wt = torch.randn(Cout, Cin, 3, 3) / (Cin * 9) ** 0.5 * sw
+    bias = torch.randn(Cout) * 0.1 * sa * sw
+    got = eng.op_conv(nhwc(x), None, None, False, 0, wt, bias, None, False, 3)
+    r = check_conv64(got, x, wt, bias, 1)
+    print(name, FAMILY, f"err/bound {r:.3f}")
+
+
+def test_conv_domain_mixed_magnitudes_and_weight_outliers(eng):
+    """activations log-uniform over 10^-6 .. 10^4 with random signs; a weight tensor with a few 100x outliers, which push the
+    per-convolution pre-scale exponent down so that ordinary weights sit 2^7 lower in the fp16 range"""
+    torch.manual_seed(5)
+    B, Cin, Cout, H, W = 2, 256, 128, 8, 32
+    x = torch.sign(torch.randn(B, Cin, H, W)) * 10.0 ** (torch.rand(B, Cin, H, W) * 10 - 6)
+    wt = torch.randn(Cout, Cin, 3, 3) / (Cin * 9) ** 0.5
+    idx = torch.randint(0, wt.numel(), (7,))
+    wt.view(-1)[idx] *= 100.0
+    bias = torch.randn(Cout)
+    got = eng.op_conv(nhwc(x), None, None, False, 0, wt, bias, None, False, 3)
+    r = check_conv64(got, x, wt, bias, 1)
+    print("mixed magnitudes + outliers", FAMILY, f"err/bound {r:.3f}")
+    # through the fused transform too: GroupNorm coefficients that blow the activation up to ~10^3 before SiLU
+    coef = torch.stack([torch.randn(B, Cin) * 0.2, 300.0 * (1 + 0.2 * torch.randn(B, Cin)), torch.randn(B, Cin)])
+    x2 = torch.randn(B, Cin, H, W)
+    v = F.silu(((x2.double() - coef[0].double()[:, :, None, None]) * coef[1].double()[:, :, None, None] + coef[2].double()[:, :, None, None]))
+    got = eng.op_conv(nhwc(x2), None, coef.cuda(), True, 0, wt, bias, None, False, 3)
+    # the transform itself runs in fp32 on the device (affine + SiLU: a few ulp of |v|): widen the bound by 2^-21 |v| per operand
+    v64, w64 = v, wt.double()
+    ref = F.conv2d(v64, w64, bias.double(), padding=1)
+    lim = conv_bound(v64, w64, 1) + 2.0 ** -20 * F.conv2d(v64.abs(), w64.abs(), None, padding=1)
+    err = (nchw(got).double() - ref).abs()
+    assert float((err / lim).max()) <= 1.0, float((err / lim).max())
+
+
+def test_conv_skip_segment_with_large_raw_residual_stream(eng):
+    """the fused 1x1 skip_connection reads the RAW residual stream (no GroupNorm in front of it, OpenAI_Unet.py:338): feed it
+    magnitudes of 10^3..10^4 next to an O(1) main segment; both weight tensors share one pre-scale exponent"""
+    torch.manual_seed(11)
+    B, Cin, S0, Cout, H, W = 2, 128, 256, 128, 8, 32
+    x = torch.randn(B, Cin, H, W)
+    sk = torch.randn(B, S0, H, W) * 10.0 ** (3 + torch.rand(B, S0, H, W))
+    wt = torch.randn(Cout, Cin, 3, 3) / (Cin * 9) ** 0.5
+    ws = torch.randn(Cout, S0, 1, 1) / S0 ** 0.5
+    bias = torch.randn(Cout)
+    got = eng.op_conv_skip(nhwc(x), None, False, wt, bias, nhwc(sk), ws)
+    extra = F.conv2d(sk.double(), ws.double())
+    r = check_conv64(got, x, wt, bias, 1, extra=extra, extra_bound=conv_bound(sk.double(), ws.double(), 0))
+    print("skip segment, raw stream 1e3..1e4", FAMILY, f"err/bound {r:.3f}")
+
+
+def test_conv_beyond_the_fp16_range_is_loud(eng):
+    """|activation| >= 65504 is outside the default family's domain: the result must be NON-FINITE (never a finite wrong
+    number); the exact families compute it. 65000 (inside) must still meet the bound."""
+    torch.manual_seed(3)
+    B, Cin, Cout, H, W = 1, 128, 128, 8, 32
+    wt = torch.randn(Cout, Cin, 3, 3) / (Cin * 9) ** 0.5
+    bias = torch.zeros(Cout)
+    x = torch.randn(B, Cin, H, W)
+    x[0, 5, 3, 7] = 65000.0
+    check_conv64(eng.op_conv(nhwc(x), None, None, False, 0, wt, bias, None, False, 3), x, wt, bias, 1)
+    x[0, 5, 3, 7] = 1.0e5
+    got = nchw(eng.op_conv(nhwc(x), None, None, False, 0, wt, bias, None, False, 3))
+    if FAMILY == "h3":
+        bad = ~torch.isfinite(got)
+        assert bool(bad[0, :, 2:5, 6:9].all()), "every output that reads the out-of-range activation must be non-finite"
+        assert bool(torch.isfinite(got[0, :, 6:, 20:]).all())
+    else:
+        check_conv64(nhwc(got), x, wt, bias, 1)
+
+
+@pytest.mark.parametrize("ratio", [0.0, 10.0, 100.0])
+def test_groupnorm_statistics_from_the_conv_epilogue_with_large_mean(eng, ratio):
+    """GroupNorm statistics come from the producing convolution's epilogue as fp32 per-tile records, folded in fp64
+    (conv_x6.hip epilogue, norm_kernels.hip). A channel group with |mean| >> sigma is the hard case: here the conv bias
+    puts the output mean at ratio * sigma. Reference: float64 statistics of the conv OUTPUT AS STORED (isolates the
+    statistics path from the convolution's own rounding). Bound on the normalised value: 1e-5 * (1 + ratio)."""
+    torch.manual_seed(int(ratio) + 1)
+    B, Cin, Cout, H, W = 2, 128, 256, 16, 32
+    x = torch.randn(B, Cin, H, W)
+    wt = torch.randn(Cout, Cin, 3, 3) / (Cin * 9) ** 0.5          # output sigma ~ 1
+    bias = ratio * (1 + 0.05 * torch.randn(Cout))
+    gamma, beta = 1 + 0.1 * torch.randn(Cout), 0.1 * torch.randn(Cout)
+    out, coef = eng.op_conv_gn(nhwc(x), wt, bias, gamma, beta)
+    o64 = nchw(out).double()
+    coef = coef.cpu().double()
+    ref = F.group_norm(o64, 32, gamma.double(), beta.double(), eps=1e-5)
+    got = (o64 - coef[0][:, :, None, None]) * coef[1][:, :, None, None] + coef[2][:, :, None, None]
+    err = float((got - ref).abs().max())
+    print(f"|mean|/sigma = {ratio:g}: normalised-value max err {err:.3e}")
+    assert err <= 1e-5 * (1 + ratio), err

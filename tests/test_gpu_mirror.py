@@ -134,3 +134,47 @@ def test_ddpm2d_reconstruct_switch(sd_np, synth):
     out = mod.test_step({"vol": {"data": inp.permute(1, 2, 3, 0).unsqueeze(0)}}, 0)
     assert out["final_volume"].shape == (1, 1, 32, 32, 3)
     mod.diffusion.model._hip.close()
+
+
+def test_ddpm2d_test_step_noise_ensemble_vs_oracle_composition(sd_np, synth, oracle, sd_torch):
+    """The package's own LightningModule with the reference experiment's cfg (noise_ensemble: True, noisetype: simplex,
+    configs/experiment/cDDPM/DDPM_cond_spark_2D.yaml:22,33) against a composition of the already-golden pieces: the 4 centre
+    slices, three single-step reconstructions (oracle p_losses_recon, golden-pinned) at t = 249, 499, 749, each from the
+    simplex field of the seed numpy's RNG yields at that point (simplex oracle, bit-exact golden), averaged."""
+    import simplex_oracle as SO
+    M = load_pkg("DDPM_2D")
+    GN = load_pkg("generate_noise")
+    cfg = dict(imageDim=[64, 64, 100], rescaleFactor=2, unet_dim=128, dim_mults=[1, 2, 2], condition=True,
+               test_timesteps=500, timesteps=1000, noise_ensemble=True, noisetype="simplex")
+
+    class Enc(torch.nn.Module):          # stand-in for the context encoder (row f2 has its own tests)
+        def forward(self, x):
+            return x.flatten(1)[:, :128].contiguous() * 2 - 1
+
+    mod = M.DDPM_2D(cfg, encoder=Enc())
+    mod.diffusion.model.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()})
+    mod = mod.cuda()
+    D, H, W = 9, 32, 32
+    vol = torch.from_numpy(synth.synth_slices(2, 0, D, H, W)).permute(1, 2, 3, 0).unsqueeze(0).contiguous()   # [1,1,H,W,D]
+    np.random.seed(2024)
+    out = mod.test_step({"vol": {"data": vol.cuda()}}, 0)
+    got = out["final_volume"].cpu()[0, 0].permute(2, 0, 1).unsqueeze(1)                  # [4,1,H,W]
+    # oracle composition
+    start = int((D - 4) / 2)
+    x01 = vol[0, 0].permute(2, 0, 1).unsqueeze(1)[start:start + 4].contiguous()
+    assert torch.equal(out["input"].cpu(), x01) and out["ind_offset"] == start
+    cond = Enc()(x01)
+    buf = oracle.schedule_buffers(1000)
+    np.random.seed(2024)
+    acc = torch.zeros_like(x01)
+    for t in (250, 500, 750):
+        GN.draw_seed()
+        seed = GN.draw_seed()
+        noise = torch.from_numpy(SO.gen_noise(seed, (4, 1, H, W))).float()
+        _loss, reco = oracle.p_losses_recon(x01, torch.full((4,), t - 1), cond, noise, sd_torch, buf)
+        acc += reco
+    ref = acc / 3
+    err = float((got - ref).abs().max())
+    print(f"test_step (noise ensemble, simplex) vs oracle composition: max|delta| {err:.3e}")
+    assert err < TOL and float(ref.std()) > 0.01
+    mod.diffusion.model._hip.close()

@@ -127,6 +127,56 @@ def test_ddpm2d_mirror_builds_from_experiment_cfg():
         M.DDPM_2D(dict(cfg, backbone="resnet101"))
 
 
+def test_ddpm2d_test_step_follows_the_reference_call_sequence(monkeypatch):
+    """src/models/DDPM_2D.py:171-286 with the experiment's cfg (noise_ensemble: True, noisetype: simplex): the 4 CENTRE
+    slices (:193-200), one fresh gen_noise field per ensemble member (:231), self.diffusion(input, cond=features, t=t-1,
+    noise=noise) at t in [250, 500, 750] (:235), the mean of the three reconstructions (:238), volume as [1,1,H,W,D].
+    Host logic only: the diffusion and the noise generator are recorders."""
+    M = load_pkg("DDPM_2D")
+    cfg = dict(imageDim=[64, 64, 100], rescaleFactor=2, unet_dim=128, dim_mults=[1, 2, 2], condition=True,
+               test_timesteps=500, noise_ensemble=True, spatial_transformer=False, noisetype="simplex")
+    enc = torch.nn.Sequential(torch.nn.Flatten(), torch.nn.LazyLinear(128))
+    mod = M.DDPM_2D(cfg, encoder=enc)
+    calls, draws = [], []
+
+    class FakeDiffusion(torch.nn.Module):
+        def forward(self, img, cond=None, t=None, noise=None):
+            calls.append((tuple(img.shape), tuple(cond.shape), int(t), None if noise is None else float(noise.flatten()[0])))
+            return torch.tensor(float(t)), torch.full_like(img, float(t))
+
+        def _engine(self, B, H, W, device):
+            return "engine"
+
+    def fake_gen_noise(cfg_, shape, engine=None, **kw):
+        assert engine == "engine" and cfg_ is mod.cfg
+        draws.append(tuple(shape))
+        return torch.full(tuple(shape), float(len(draws)), dtype=torch.float16)
+
+    mod.diffusion = FakeDiffusion()
+    monkeypatch.setattr(M, "gen_noise", fake_gen_noise)
+    D = 10
+    vol = torch.arange(D, dtype=torch.float32).reshape(1, 1, 1, 1, D).expand(1, 1, 32, 32, D).contiguous()
+    out = mod.test_step({"vol": {"data": vol}}, 0)
+    assert mod.cfg["num_eval_slices"] == 4 and out["ind_offset"] == 3                 # int((10 - 4) / 2)
+    assert out["input"].shape == (4, 1, 32, 32) and out["input"][:, 0, 0, 0].tolist() == [3.0, 4.0, 5.0, 6.0]
+    assert [c[2] for c in calls] == [249, 499, 749] and out["timesteps"] == [250, 500, 750]
+    assert draws == [(4, 1, 32, 32)] * 3 and [c[3] for c in calls] == [1.0, 2.0, 3.0]      # a FRESH field per member
+    assert all(c[0] == (4, 1, 32, 32) and c[1] == (4, 128) for c in calls)
+    assert out["final_volume"].shape == (1, 1, 32, 32, 4)
+    assert torch.allclose(out["final_volume"], torch.full((1, 1, 32, 32, 4), (249 + 499 + 749) / 3.0))
+    assert float(out["loss"]) == 749.0                                               # the last member's loss (:235, :249)
+    # step_ensemble override, and the single reconstruction at test_timesteps when noise_ensemble is off
+    calls.clear(); draws.clear()
+    mod.cfg["step_ensemble"] = [100, 900]
+    mod.test_step({"vol": {"data": vol}}, 0)
+    assert [c[2] for c in calls] == [99, 899] and len(draws) == 2
+    calls.clear(); draws.clear()
+    mod.cfg["noise_ensemble"] = False
+    mod.cfg["noisetype"] = None
+    out = mod.test_step({"vol": {"data": vol[..., :4]}}, 0)                          # exactly 4 slices: no selection
+    assert [c[2] for c in calls] == [499] and draws == [] and calls[0][3] is None and out["ind_offset"] == 0
+
+
 def test_encoder_mirror_inventory_and_oracle_shapes(synth):
     """timm resnet50 (in_chans=1) inventory: 161 weight tensors + 53 x (running_mean, running_var, num_batches_tracked);
     the oracle restatement runs on the synthetic weights and is sensitive to every stage."""
