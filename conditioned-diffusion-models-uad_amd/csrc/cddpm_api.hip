@@ -98,6 +98,8 @@ struct cddpm_ctx {
     float *bufA = nullptr, *bufB = nullptr, *bufH = nullptr, *bufP0 = nullptr, *bufP1 = nullptr;
     float *qkvbuf = nullptr, *attbuf = nullptr, *headP = nullptr, *model_out = nullptr;
     float* coef = nullptr;
+    float* kpart = nullptr;              // split-K planes of the small-batch plan (see plan_ksplit)
+    int cur_H = 0, cur_W = 0;            // image size of the forward in flight (a layer's downsampling factor follows from it)
     // GroupNorm statistics records per activation buffer (written by the producing conv's epilogue, or by the
     // stand-alone sweep): buffer -> records storage, and how many records are valid in the current forward
     std::map<const float*, float*> stat_buf;
@@ -176,9 +178,59 @@ double conv_bytes(const ConvArgs& a) {
     b += (double)a.Cout * ((double)(a.C0 + a.C1) * a.taps + a.S0 + a.S1);
     return 4.0 * b;
 }
+// Small-batch plan (fp16-split family). A layer launches B * tiles * (Cout / 128) workgroups of 256 pixels x 128 channels; when the
+// HANDLE's largest geometry gives fewer than half the chip's 256 CUs a workgroup, the K loop of that layer is cut into S ranges run
+// by S workgroups per tile (plane j of `kpart` each) and conv_reduce_kernel adds the planes in the order of j. S is a property of
+// the handle (max_batch, max_h, max_w and the layer), never of the call: a slice's bits do not depend on the batch it is in, as long
+// as it is computed on handles of the same maximum geometry (sharded runs: the same engine configuration on every rank).
+constexpr int KSPLIT_PLANE_FLOATS = 256 * 256 * 128;      // S * workgroups <= 256, a workgroup's tile <= 256 x 128 outputs
+int plan_ksplit(const cddpm_ctx* h, const ConvArgs& a, short* kbound) {
+    static const bool off = [] { const char* e = getenv("CDDPM_KSPLIT"); return e && e[0] == '0'; }();
+    if (off || conv_mode() != 2 || h->cur_H <= 0) return 1;
+    const bool up2 = (a.taps == 4);
+    const int Hm = (int)((long long)a.H * h->d.max_h / h->cur_H), Wm = (int)((long long)a.W * h->d.max_w / h->cur_W);
+    const int gh = up2 ? Hm / 2 : Hm, gw = up2 ? Wm / 2 : Wm;
+    const long long nwg = (long long)h->d.max_batch * (up2 ? 4 : 1) * ((gw + 31) / 32) * ((gh + 7) / 8) * (a.Cout / 128);
+    const int nch_main = (a.C0 + a.C1) / 32, nch_skip = (a.S0 + a.S1) / 32, nch = nch_main + nch_skip;
+    const int units = nch_main * a.taps + nch_skip;           // taps to multiply per tile
+    int S = 1;
+    while (S < CDDPM_MAX_KSPLIT && nwg * (S * 2) <= 256 && units / (S * 2) >= 9 && S * 2 <= nch) S *= 2;
+    if (S == 1) return 1;
+    // consecutive chunk ranges of about units / S taps each, none empty
+    int c = 0, acc = 0;
+    kbound[0] = 0;
+    for (int j = 1; j < S; ++j) {
+        const int target = (int)((long long)units * j / S);
+        while (c < nch - (S - j) && acc + (c < nch_main ? a.taps : 1) / 2 < target) { acc += (c < nch_main ? a.taps : 1); ++c; }
+        if (c <= kbound[j - 1]) { acc += (c < nch_main ? a.taps : 1); ++c; }
+        kbound[j] = (short)c;
+    }
+    kbound[S] = (short)nch;
+    return S;
+}
+
 int conv_launch(cddpm_ctx* h, ConvArgs a, hipStream_t s) {
     auto it = h->stat_buf.find(a.out);       // outputs that can feed a GroupNorm get their statistics for free
     a.stats = (it != h->stat_buf.end()) ? it->second : nullptr;
+    short kb[CDDPM_MAX_KSPLIT + 1] = {0};
+    const int S = plan_ksplit(h, a, kb);
+    if (S > 1) {
+        if ((size_t)S * a.B * a.H * a.W * a.Cout > (size_t)KSPLIT_PLANE_FLOATS)
+            return fail(h, "split-K planes of a %dx%dx%d conv output (B=%d, S=%d) exceed the workspace", a.H, a.W, a.Cout, a.B, S);
+        const int nrec_r = conv_reduce_stat_records(a.H, a.W);
+        if (a.stats && (size_t)a.B * nrec_r * a.Cout * 2 > h->stat_cap.at(a.out))
+            return fail(h, "GroupNorm statistics records of a %dx%dx%d conv output do not fit their buffer", a.H, a.W, a.Cout);
+        ConvArgs k = a;
+        k.out = h->kpart; k.bias = nullptr; k.res = nullptr; k.stats = nullptr; k.ksplit = S;
+        for (int j = 0; j <= S; ++j) k.kbound[j] = kb[j];
+        {
+            Prof p(h, a.taps == 1 ? PC_CONV1 : PC_CONV3, conv_flops(a), conv_bytes(a), s);
+            launch_conv(k, s);
+            launch_conv_reduce(h->kpart, S, a.bias, a.res, a.res_up, a.out, a.stats, a.B, a.H, a.W, a.Cout, s);
+        }
+        if (a.stats) h->stat_n[a.out] = nrec_r;
+        return 0;
+    }
     const int nrec = (a.taps == 4) ? conv_stat_records_up2(a.H, a.W) : conv_stat_records(a.H, a.W);
     if (a.stats) {
         // a statically sized buffer against a shape-derived count: refuse to launch rather than write past the end
@@ -459,6 +511,7 @@ size_t plan_workspace(cddpm_ctx* h, bool do_alloc, int* rc) {
         }
     }
     want(&h->coef, 3 * B * maxC);
+    want(&h->kpart, (size_t)KSPLIT_PLANE_FLOATS);
     // tables and embedding scratch
     const size_t rows = std::max<size_t>(d.timesteps, B);
     want(&h->tab, (size_t)d.timesteps * h->sumE);
@@ -624,6 +677,7 @@ int check_call(cddpm_ctx* h, int B, int H, int W) {
 // UNetModel.forward (OpenAI_Unet.py:823-1006); d_t must hold the per-sample timesteps.
 int forward_impl(cddpm_ctx* h, const float* x, float* out, int B, int H, int W, hipStream_t s) {
     h->stat_n.clear();        // no tensor of this forward has statistics yet
+    h->cur_H = H; h->cur_W = W;
     std::vector<int> stack;   // indices into h->hs
     int npush = 0;
     const float* cur = nullptr;

@@ -177,6 +177,11 @@ __global__ __launch_bounds__(64 * ROWS) void conv_split_kernel(const ConvArgs a)
 #endif
     const int cb = bid % ncb;
     bid /= ncb;
+    // split-K (small batches, cddpm_api.hip::conv_launch): this workgroup multiplies the chunks kbound[ks] .. kbound[ks + 1] only
+    // and stores its raw sums to plane ks of `out`; conv_reduce_kernel adds the planes in the order of ks
+    const int nks = a.ksplit > 1 ? a.ksplit : 1;
+    const int ks = bid % nks;
+    bid /= nks;
     const int tx = bid % tilesX;
     bid /= tilesX;
     const int ty = bid % tilesY;
@@ -211,6 +216,8 @@ __global__ __launch_bounds__(64 * ROWS) void conv_split_kernel(const ConvArgs a)
     const int nch_main = Cin >> 5;
     const int nch_skip = (a.S0 + a.S1) >> 5;
     const int nch = nch_main + nch_skip;
+    const int kc0 = a.ksplit > 1 ? a.kbound[ks] : 0;          // first chunk of this workgroup
+    const int kc1 = a.ksplit > 1 ? a.kbound[ks + 1] : nch;    // one past its last chunk
 
     // ---- per-thread patch entries: channel quad c4 is fixed per thread, pixel q = (tid>>3) + (THREADS/8) k
     const int c4 = tid & 7;
@@ -529,10 +536,10 @@ __global__ __launch_bounds__(64 * ROWS) void conv_split_kernel(const ConvArgs a)
     };
     int nsl_cur = 0;
     {
-        const v4f* p0 = wstage(0, 0, nsl_cur);
+        const v4f* p0 = wstage(kc0, 0, nsl_cur);
         dma_stage(p0, nsl_cur, 0);
     }
-    load_act(0);
+    load_act(kc0);
     if (have_coef) {
         const int nq = Cin >> 2;
         const size_t plane = (size_t)a.B * Cin;
@@ -542,22 +549,32 @@ __global__ __launch_bounds__(64 * ROWS) void conv_split_kernel(const ConvArgs a)
         }
     }
     int buf = 0;
+#ifdef CDDPM_STAGGER_SLEEP
+    // A/B switch (tools/conv_ab.py): the two waves of a SIMD (w and w + 4) run the same program between the same barriers;
+    // waves 4-7 start every stage 64 * CDDPM_STAGGER_SLEEP cycles late so that their fragment reads fall behind their partner's
+    // (MI355X_MICROARCH.md, Two waves per SIMD, item 9). Results unchanged.
+    const bool late = __builtin_amdgcn_readfirstlane(wave) >= 4;
+#define STAGGER() { if (late) __builtin_amdgcn_s_sleep(CDDPM_STAGGER_SLEEP); }
+#else
+#define STAGGER()
+#endif
     STAMP(0)
-    for (int chunk = 0; chunk < nch; ++chunk) {
+    for (int chunk = kc0; chunk < kc1; ++chunk) {
         const bool main_seg = chunk < nch_main;
         const int nst = main_seg ? TAPS / TPS : 1;       // stages of this chunk
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this chunk's first weight stage (and its patch registers) have landed
         LOOP_BARRIER();   // ... in every wave, and every wave is done reading the previous patch
         store_act(chunk);
         LOOP_BARRIER();
+        STAGGER();
         STAMP(1)
         for (int st = 0; st < nst; ++st) {
             const int ntaps = nsl_cur;                    // taps of this stage
             const bool last_st = (st == nst - 1);
             int nsl_next = 0;
             // (patch loads first: with a DMA in flight the compiler drains vmcnt to 0 in front of ordinary loads)
-            if (last_st && chunk + 1 < nch) load_act(chunk + 1);
-            if (!(last_st && chunk + 1 >= nch)) {         // (nothing may be in flight when the epilogue reuses the buffers)
+            if (last_st && chunk + 1 < kc1) load_act(chunk + 1);
+            if (!(last_st && chunk + 1 >= kc1)) {         // (nothing may be in flight when the epilogue reuses the buffers)
                 const v4f* pn = last_st ? wstage(chunk + 1, 0, nsl_next) : wstage(chunk, st + 1, nsl_next);
                 dma_stage(pn, nsl_next, buf ^ 1);
             }
@@ -580,6 +597,7 @@ __global__ __launch_bounds__(64 * ROWS) void conv_split_kernel(const ConvArgs a)
             if (!last_st) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 LOOP_BARRIER();   // the next stage has landed in every wave; this stage's buffer is free
+                STAGGER();
             }
         }
     }
@@ -736,7 +754,7 @@ __global__ __launch_bounds__(64 * ROWS) void conv_split_kernel(const ConvArgs a)
                     const int gy = y0 + 2 * wm + (p >> 5), gx = x0 + (p & 31);
                     ok[i] = (gy < gridH) && (gx < gridW);
                     const int y = UP2 ? (2 * gy + pa) : gy, x = UP2 ? (2 * gx + pb) : gx;
-                    oidx[i] = ((size_t)(b * a.H + y) * a.W + x) * a.Cout + co;
+                    oidx[i] = ((size_t)((ks * a.B + b) * a.H + y) * a.W + x) * a.Cout + co;
                     val[i] = *reinterpret_cast<const v4f*>(tr + p * TRS + 4 * cq);
                 }
 #pragma unroll
@@ -794,7 +812,7 @@ static void launch_split(const ConvArgs& a, hipStream_t stream) {
     const bool up2 = (a.taps == 4);
     const int gh = up2 ? a.H / 2 : a.H, gw = up2 ? a.W / 2 : a.W;
     const int tilesX = (gw + 31) / 32, tilesY = (gh + ROWS - 1) / ROWS;
-    const unsigned grid = (unsigned)(a.B * (up2 ? 4 : 1) * tilesX * tilesY * (a.Cout / 128));
+    const unsigned grid = (unsigned)(a.B * (up2 ? 4 : 1) * tilesX * tilesY * (a.Cout / 128) * (a.ksplit > 1 ? a.ksplit : 1));
     const size_t coef_lds = a.coef ? (size_t)3 * (a.C0 + a.C1) * sizeof(float) : 0;
     auto need = [&](int npix) {
         const int tps = (NS == 2) ? (a.taps == 9 ? 3 : (a.taps == 4 ? 2 : 1)) : 1;     // taps per weight stage (kernel: TPS)

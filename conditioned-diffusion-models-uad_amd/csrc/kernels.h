@@ -10,6 +10,7 @@ namespace cddpm {
 // Fused implicit-GEMM convolution (conv_mfma.hip). NHWC activations, M = pixels, N = output channels,
 // K = taps x input channels, v_mfma_f32_32x32x2_f32 (exact fp32).
 // ------------------------------------------------------------------------------------------------
+#define CDDPM_MAX_KSPLIT 8
 struct ConvArgs {
     const float* src0;   // NHWC [B, srcH, srcW, C0]
     const float* src1;   // NHWC [B, srcH, srcW, C1] or nullptr: channels C0.. of the concatenation
@@ -35,7 +36,17 @@ struct ConvArgs {
     // [B][nrec = 2 * tilesX * tilesY][Cout][2] = per-channel (sum, sum of squares) over the 64 pixels a wave owns
     float* stats;
     float wscale_inv;    // conv_mode() == 2: 2^-wexp of the packed weights (main and skip segment share it); else unused
+    // split-K (fp16-split family only; 0 / 1 = off): the K loop (32-channel chunks of the main segment, then of the skip segment)
+    // is cut into `ksplit` consecutive ranges kbound[j] .. kbound[j + 1]; workgroup (tile, j) stores its scaled raw sums to plane j
+    // of `out` ([ksplit][B][H][W][Cout]; the caller passes no bias / residual / stats) and launch_conv_reduce combines the planes.
+    int ksplit;
+    short kbound[CDDPM_MAX_KSPLIT + 1];
 };
+// out[b][p][c] = ((plane 0 + plane 1) + ...) + bias[c] + residual, in this fixed order; optional GroupNorm statistics records of
+// `out`: one record per 64 consecutive pixels, [B][ceil(HW / 64)][Cout][2]
+void launch_conv_reduce(const float* planes, int ksplit, const float* bias, const float* res, int res_up, float* out, float* stats,
+                        int B, int H, int W, int Cout, hipStream_t stream);
+inline int conv_reduce_stat_records(int H, int W) { return (H * W + 63) / 64; }
 #define CDDPM_STAT_FLOATS 2      // floats per (record, channel): (sum, sum of squares)
 inline int conv_stat_records(int H, int W) { return 2 * ((W + 31) / 32) * ((H + 3) / 4); }
 inline int conv_stat_records_up2(int H, int W) { return 8 * ((W / 2 + 31) / 32) * ((H / 2 + 3) / 4); }

@@ -171,19 +171,40 @@ def test_sharding_invariance(eng1000, synth):
     assert torch.equal(full[:2], lo) and torch.equal(full[2:], hi)
 
 
-def test_full_batch_is_the_concatenation_of_small_batches(engine_factory, eng1000, synth):
+def test_full_batch_is_the_concatenation_of_small_batches(engine_factory, synth):
     """BASELINE config 2's size (64 slices of 128x128 on one GPU) through a size-independent property: every slice of
-    the B = 64 run equals, bit for bit, the same slice reconstructed in a batch of 4 (golden-pinned geometry), and the
-    first four also match the reference-pinned oracle path indirectly through test_reverse_loop_golden."""
+    the B = 64 run equals, bit for bit, the same slice reconstructed in a batch of 4 on the same handle (the kernel plan --
+    tile order, split-K factors -- is a property of the handle's maximum geometry, never of the call's batch). The
+    full-length version of this check is tests/test_gpu_headline.py."""
     eng = engine_factory(timesteps=1000, max_batch=64, max_h=128, max_w=128)
     H = W = 128
     x, cond = inputs(synth, 64, H, W)
     full = eng.reverse(x.cuda(), cond.cuda(), 3, seed=11, slice0=0)
     assert bool(torch.isfinite(full).all()) and float(full.std()) > 0.01
     for s0 in (0, 28, 60):
-        part = eng1000.reverse(x[s0:s0 + 4].cuda(), cond[s0:s0 + 4].cuda(), 3, seed=11, slice0=s0)
+        part = eng.reverse(x[s0:s0 + 4].cuda(), cond[s0:s0 + 4].cuda(), 3, seed=11, slice0=s0)
         assert torch.equal(full[s0:s0 + 4], part), s0
     eng.close()
+
+
+def test_small_batch_plan_and_large_batch_plan_agree_to_rounding(engine_factory, eng1000, synth):
+    """A handle sized for small batches (max_batch 4) cuts the K loop of the layers that cannot fill the chip into split-K
+    ranges (cddpm_api.hip::plan_ksplit) -- a different summation order from a max_batch 64 handle, so the two agree to fp32
+    rounding, not bit for bit; each is checked against the reference goldens on its own (eng1000 here and in every golden
+    test above: split; the 64-handle: unsplit, also tests/test_gpu_headline.py). Within one handle the bits never depend on B."""
+    big = engine_factory(timesteps=1000, max_batch=64, max_h=128, max_w=128)
+    for (B, H, W) in ((2, 32, 32), (1, 128, 128)):
+        g = golden(f"unet_fwd_B{B}_{H}x{W}")
+        x, cond = inputs(synth, B, H, W)
+        a = eng1000.unet_forward(x.cuda(), 500, cond.cuda()).cpu().numpy()
+        b = big.unet_forward(x.cuda(), 500, cond.cuda()).cpu().numpy()
+        ea, eb, eab = np.abs(a - g["t500"]).max(), np.abs(b - g["t500"]).max(), np.abs(a - b).max()
+        print(f"{B}x{H}x{W}: split-K plan vs golden {ea:.2e}, unsplit plan vs golden {eb:.2e}, between them {eab:.2e}")
+        assert ea < TOL and eb < TOL and eab < 2e-5
+    x, cond = inputs(synth, 4, 64, 96)
+    one = torch.cat([eng1000.unet_forward(x[i:i + 1].cuda(), 321, cond[i:i + 1].cuda()) for i in range(4)])
+    assert torch.equal(one, eng1000.unet_forward(x.cuda(), 321, cond.cuda()))
+    big.close()
 
 
 def test_errors_are_loud(eng1000, synth):

@@ -4,7 +4,7 @@ third argument = another kernel-name substring, e.g. "conv_mfma_kernel<9" for CD
 
 Applies the gfx950 corrections of MI355X_MICROARCH.md: FETCH_SIZE (KB) under-reports wide (16 B/lane) coalesced
 reads by exactly 2x -> doubled; WRITE_SIZE (KB) is exact for 16-B-per-lane stores. Writes
-profiles/conv3x3_hbm_traffic.json (read by bench.py for roofline.traffic) and prints the utilisation figures.
+profiles/<round>_conv3x3_hbm_traffic.json (read by bench.py for roofline.traffic, labelled with its source) and prints the utilisation figures.
 usage: python tools/pmc_summary.py gpurun_out profiles/r01_pmc_summary.json [kernel-substring]"""
 import collections
 import csv
@@ -50,6 +50,6 @@ res["hbm_write_bytes_per_launch"] = write
 res["bytes_per_launch"] = fetch + write
 json.dump(res, open(out, "w"), indent=1)
 json.dump({"bytes_per_launch": fetch + write, "fetch": fetch, "write": write,
-           "note": "rocprofv3 FETCH_SIZE x2 (gfx950 wide-read correction) + WRITE_SIZE, average over the conv3x3 launches of one reverse step, B=64 128x128"},
-          open(os.path.join(os.path.dirname(out), "conv3x3_hbm_traffic.json"), "w"), indent=1)
+           "note": "rocprofv3 FETCH_SIZE x2 (gfx950 wide-read correction) + WRITE_SIZE, average over the conv3x3 launches of 50 reverse steps, B=64 128x128"},
+          open(os.path.join(os.path.dirname(out), os.path.basename(out).split("_")[0] + "_conv3x3_hbm_traffic.json"), "w"), indent=1)
 print(json.dumps(res, indent=1))
