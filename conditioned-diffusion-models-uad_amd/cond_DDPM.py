@@ -17,7 +17,8 @@ Differences, on purpose:
     never assigns it, so its own p_sample crashes; this is the intended semantics (experiment yaml :31);
   * the simplex branch (`noise is not None`, :441-443, :450-452) draws its fields on the device (csrc/simplex.hip,
     bit-exact with the reference's CPU generator for a given seed) instead of numba + host->device copies per step;
-    `box` in-painting is outside the accelerated path and raises NotImplementedError; DDIM (`ddim_sample`) is accelerated;
+    `box` in-painting is outside the accelerated path and raises NotImplementedError (the reference's `ddim_sample_box` does
+    not exist, :527); DDIM (`ddim_sample`) is accelerated, with Gaussian or simplex per-step noise as `cfg.noisetype` says;
   * noise: x_T and z_t come from the counter RNG (synth.py / on-device Philox) seeded from torch's global
     generator, so `torch.manual_seed` still makes runs reproducible; pass `seed=`/`slice0=` to pin them.
 """
@@ -128,10 +129,9 @@ class GaussianDiffusion(nn.Module):
     @torch.no_grad()
     def p_sample(self, x, t: int, clip_denoised=True, cond=None, cond_scale=1., noise=None, *, z=None, seed=None, slice0=0):
         """x_t -> x_{t-1} (cond_DDPM.py:432-444). `z`: this step's N(0,1) draw (else drawn on the device)."""
-        if not clip_denoised:
-            raise NotImplementedError("clip_denoised=False is not part of the reconstruction path")
         B, _c, H, W = x.shape
         eng = self._engine(B, H, W, x.device)
+        eng.set_clip_denoised(clip_denoised)
         if noise is not None:
             # reference :441-443: the passed tensor only selects the branch; a NEW simplex field is drawn for the step
             z = gen_noise(self.cfg, x.shape, engine=eng).float() if t > 0 else None
@@ -163,10 +163,12 @@ class GaussianDiffusion(nn.Module):
             img = (_extract(self.sqrt_alphas_cumprod, tT, x_start.shape) * x_start.float()
                    + _extract(self.sqrt_one_minus_alphas_cumprod, tT, x_start.shape) * field)[:, 0].unsqueeze(1).contiguous()
             eng.prepare_cond(cond.float() if cond is not None else None, B)
+            eng.set_clip_denoised(True)
             for t in reversed(range(0, T)):
                 z = gen_noise(self.cfg, (B, 1, H, W), engine=eng).float() if t > 0 else None
                 img = eng.p_sample(img, t, None, z=z)
             return unnormalize_to_zero_to_one(img)
+        eng.set_clip_denoised(True)                       # p_sample_loop calls p_sample with its default clip_denoised (:461)
         seed = self._draw_seed(seed)
         if x_T is None:
             x_T = eng.noise_fill(B, H, W, seed=seed, stream_id=_synth.STREAM_XT, slice0=slice0)
@@ -193,18 +195,23 @@ class GaussianDiffusion(nn.Module):
     def ddim_sample(self, shape, clip_denoised=True, cond=None, cond_scale=1., x_start=None, start_t=0, noise=None, *,
                     x_T=None, z_noise=None, seed=None, slice0=0, device=None):
         """DDIM sampling (cond_DDPM.py:466-515) over sampling_timesteps + 1 time pairs, one UNet call per pair.
-        Gaussian branch; start_t != 0 starts from q_sample(x_start, t = start_t, x_T) as the reference does (:482).
+        start_t != 0 starts from q_sample(x_start, t = start_t, noise) as the reference does (:482): `noise` is then the
+        q_sample noise itself (a passed tensor is used as given; None draws N(0,1), i.e. x_T). The per-step z follows
+        `cfg.noisetype` exactly like the reference (:501-504): 'simplex' draws a fresh simplex field per pair (device
+        generator, generate_noise.py mirror), anything else N(0,1). `clip_denoised=False` skips the clamp of x0 (:493).
         Extras: x_T (the initial N(0,1) draw), z_noise (dict time -> [B,1,H,W] or a [num_timesteps,B,1,H,W] tensor indexed
         by `time`) inject given draws; otherwise the device Philox is keyed by (seed, time, slice0 + b)."""
-        if not clip_denoised:
-            raise NotImplementedError("clip_denoised=False is not part of the reconstruction path")
-        if noise is not None:
-            raise NotImplementedError("DDIM with simplex noise (cond_DDPM.py:477, :502) is not accelerated")
         B, _c, H, W = shape
         dev = torch.device(device) if device is not None else (cond.device if cond is not None else self.betas.device)
         eng = self._engine(B, H, W, dev)
+        eng.set_clip_denoised(clip_denoised)
         seed = self._draw_seed(seed)
         pairs = self.ddim_time_pairs(start_t)
+        noisetype = None
+        if self.cfg is not None:
+            noisetype = self.cfg.get("noisetype", None) if hasattr(self.cfg, "get") else getattr(self.cfg, "noisetype", None)
+        if noise is not None and noisetype == "simplex":
+            gen_noise(self.cfg, shape, engine=eng)          # the reference draws (and discards) one field here (:477): same seed sequence
         if x_T is None:
             x_T = eng.noise_fill(B, H, W, seed=seed, stream_id=_synth.STREAM_XT, slice0=slice0)
         img = x_T.to(dev).float().contiguous().clone()
@@ -213,16 +220,21 @@ class GaussianDiffusion(nn.Module):
                 raise ValueError("ddim_sample with start_t != 0 needs x_start")
             tT = torch.full((B,), int(start_t), device=dev, dtype=torch.long)
             xs = x_start.to(dev).float()
+            eps0 = img if noise is None else noise.to(dev).float()
             img = (_extract(self.sqrt_alphas_cumprod, tT, xs.shape) * xs
-                   + _extract(self.sqrt_one_minus_alphas_cumprod, tT, xs.shape) * img)[:, 0].unsqueeze(1).contiguous()
+                   + _extract(self.sqrt_one_minus_alphas_cumprod, tT, xs.shape) * eps0)[:, 0].unsqueeze(1).contiguous()
         eng.prepare_cond(cond.float() if cond is not None else None, B)
         for i, (time, time_next) in enumerate(pairs):
             ca, c, sigma = self.ddim_coefficients(time, time_next)
             z = None
-            if z_noise is not None and time_next > 0:
-                z = z_noise[time]
+            if time_next > 0:
+                if z_noise is not None:
+                    z = z_noise[time]
+                elif noisetype == "simplex":
+                    z = gen_noise(self.cfg, shape, engine=eng)
             eng.ddim_step(img, time, ca, c, sigma, add_noise=time_next > 0, finalize=(i == len(pairs) - 1),
                           z=z.to(dev).float().contiguous() if z is not None else None, seed=seed, slice0=slice0)
+        eng.set_clip_denoised(True)
         eng._check_finite(img, "ddim_sample")
         return img
 

@@ -90,6 +90,7 @@ struct cddpm_ctx {
     float *sched[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // coef1, coef2, logvar, sqrt_recip, sqrt_recipm1
     float *qs_sa = nullptr, *qs_s1 = nullptr;
     int objective = 0;
+    int clip_denoised = 1;               // cddpm_set_clip_denoised
     int* d_t = nullptr;
 
     // workspace
@@ -1003,7 +1004,7 @@ static int step_once(cddpm_ctx* h, float* img, const float* z_dev, uint64_t seed
     a.objective = h->objective;
     a.noise = z_dev; a.noise_t_stride = 0;
     a.seed = seed; a.slice0 = slice0; a.t_for_rng = t;
-    a.B = B; a.HW = H * W; a.finalize = finalize;
+    a.B = B; a.HW = H * W; a.finalize = finalize; a.clip = h->clip_denoised;
     launch_step(a, s);
     return 0;
 }
@@ -1038,7 +1039,7 @@ static int reverse_by_graph(cddpm_ctx* h, float* img, const float* noise_dev, ui
         a.objective = h->objective;
         a.noise = noise_dev; a.noise_t_stride = (size_t)B * H * W;
         a.seed = seed; a.slice0 = slice0; a.t_for_rng = 0;
-        a.B = B; a.HW = H * W; a.finalize = -1;
+        a.B = B; a.HW = H * W; a.finalize = -1; a.clip = h->clip_denoised;
         launch_step(a, h->gstream);
         launch_add_int(h->d_t, B, -1, h->gstream);
         hipGraph_t graph = nullptr;
@@ -1094,7 +1095,7 @@ int cddpm_ddim_step(cddpm_handle h, float* img, const float* z_dev, uint64_t see
     a.objective = h->objective;
     a.coef_x0 = coef_x0; a.coef_eps = coef_eps; a.sigma = sigma; a.add_noise = add_noise ? 1 : 0;
     a.noise = z_dev; a.seed = seed; a.slice0 = slice0;
-    a.B = B; a.HW = H * W; a.finalize = finalize ? 1 : 0;
+    a.B = B; a.HW = H * W; a.finalize = finalize ? 1 : 0; a.clip = h->clip_denoised;
     launch_ddim_step(a, s);
     HIPCHECK(h, hipGetLastError());
     return 0;
@@ -1193,6 +1194,13 @@ int cddpm_q_sample(cddpm_handle h, const float* x01_dev, const float* noise_dev,
     }
     launch_q_sample(x01_dev, noise_dev, h->d_t, h->qs_sa, h->qs_s1, out_dev, B, H * W, s);
     HIPCHECK(h, hipGetLastError());
+    return 0;
+}
+
+int cddpm_set_clip_denoised(cddpm_handle h, int on) {
+    if (!h) return -1;
+    h->gen++;                            // a captured step graph has the flag baked in
+    h->clip_denoised = on ? 1 : 0;
     return 0;
 }
 

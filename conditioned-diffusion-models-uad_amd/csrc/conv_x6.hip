@@ -9,7 +9,7 @@
 //   NS = 2, fp16 (default, CDDPM_CONV=h3):  hi = fp16(x), mid = fp16(x - hi), round-to-nearest: two 11-bit terms,
 //       |x - hi - mid| <= 2^-23 |x| (one fp32 ulp at worst; 75 % of fp32 values are reproduced exactly, rms error
 //       0.73 x 2^-24 |x|) while mid is a normal fp16, i.e. |x| >= 2^-2; below that the error is ABSOLUTE, <= 2^-25.
-//       a*b = hi*hi + hi*mid + mid*hi (+ mid*mid <= 2^-24 |ab|, dropped): 3 MFMAs
+//       a*b = hi*hi + hi*mid + mid*hi (+ mid*mid, dropped: |mid| <= 2^-11 |x|, so <= 2^-22 |ab| at worst, 2^-24 typical): 3 MFMAs
 //       (v_mfma_f32_32x32x16_f16) = 3/16 of the fp32-MFMA cost. fp16's exponent range needs care: weights are
 //       pre-scaled by a power of two chosen per convolution so that max|w| lands in [2^13, 2^14) (exact; the epilogue
 //       multiplies by the inverse), activations are used as they are -- after GroupNorm/FiLM/SiLU they are O(1), the

@@ -117,6 +117,7 @@ struct StepArgs {
     uint64_t seed, slice0; int t_for_rng;
     int B, HW;
     int finalize;                // 1: also map to [0,1]: (x+1)/2 (cond_DDPM.py:463); -1: exactly when t == 0 (graph replay)
+    int clip;                    // clip_denoised: clamp the x0 estimate to [-1,1] (the reference's default, :433)
 };
 void launch_step(const StepArgs& a, hipStream_t stream);
 // DDIM step (cond_DDPM.py:487-511): eps = (sqrt_recip[t] x - x0) / sqrt_recipm1[t] from the UNCLIPPED x0 (pred_x0 objective;
@@ -131,6 +132,7 @@ struct DdimArgs {
     uint64_t seed, slice0;
     int B, HW;
     int finalize;                     // 1: also map to [0,1] (cond_DDPM.py:513)
+    int clip;                         // clip_denoised (:467, :493-494)
 };
 void launch_ddim_step(const DdimArgs& a, hipStream_t stream);
 void launch_noise_fill(float* out, uint64_t seed, uint32_t stream_id, int t, uint64_t slice0, int B, int HW,

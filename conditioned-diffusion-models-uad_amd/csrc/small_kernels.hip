@@ -401,10 +401,12 @@ __global__ __launch_bounds__(256) void step_kernel(const StepArgs a) {
         x0.z = sr * x.z - srm1 * mo.z;
         x0.w = sr * x.w - srm1 * mo.w;
     }
-    x0.x = clamp11(x0.x);
-    x0.y = clamp11(x0.y);
-    x0.z = clamp11(x0.z);
-    x0.w = clamp11(x0.w);
+    if (a.clip) {     // clip_denoised (cond_DDPM.py:416-419, :426-427); off: the raw prediction enters the posterior mean
+        x0.x = clamp11(x0.x);
+        x0.y = clamp11(x0.y);
+        x0.z = clamp11(x0.z);
+        x0.w = clamp11(x0.w);
+    }
     const float c1 = a.coef1[t], c2 = a.coef2[t];
     // separate roundings of the two products, as the reference's tensor expression does
     float4 r;
@@ -466,7 +468,7 @@ __global__ __launch_bounds__(256) void ddim_step_kernel(const DdimArgs a) {
             eps = ms[i];
             x0 = __fsub_rn(__fmul_rn(sr, xs[i]), __fmul_rn(srm1, eps));
         }
-        x0 = clamp11(x0);
+        if (a.clip) x0 = clamp11(x0);          // clip_denoised (cond_DDPM.py:493-494)
         float r = __fadd_rn(__fmul_rn(x0, a.coef_x0), __fmul_rn(a.coef_eps, eps));
         r = __fadd_rn(r, __fmul_rn(a.sigma, zs[i]));
         if (a.finalize) r = (r + 1.f) * 0.5f;

@@ -240,6 +240,10 @@ class CddpmEngine:
                                          _stream_ptr(self.device)), "cddpm_p_sample")
         return x
 
+    def set_clip_denoised(self, on: bool):
+        """clip_denoised of p_sample / ddim_sample (cond_DDPM.py:433, :467) for every later step on this engine"""
+        self._ck(self.lib.cddpm_set_clip_denoised(self._h, int(bool(on))), "cddpm_set_clip_denoised")
+
     PROF_CLASSES = ("conv3x3_mfma", "conv1x1_mfma", "attention", "groupnorm", "other")
 
     def set_profiling(self, on: bool):

@@ -104,6 +104,11 @@ int cddpm_unet_forward(cddpm_handle h, const float* x_dev, const int32_t* t_dev,
 int cddpm_reverse(cddpm_handle h, float* img_inout_dev, const float* noise_dev, uint64_t seed,
                   uint64_t slice0, int t_start, int B, int H, int W, void* stream);
 
+/* `clip_denoised` of p_sample / ddim_sample (src/models/modules/cond_DDPM.py:433, :467): on (the reference's default, and the
+ * handle's) clamps the x0 estimate to [-1,1] before the posterior mean / the DDIM update; off uses it as predicted.
+ * Applies to every later cddpm_p_sample / cddpm_reverse / cddpm_reverse_range / cddpm_ddim_step on the handle. */
+int cddpm_set_clip_denoised(cddpm_handle h, int on);
+
 /* A segment of the same chain: steps t = t_hi, t_hi - 1, ..., t_lo (0 <= t_lo <= t_hi < T) of p_sample_loop's recurrence
  * (cond_DDPM.py:460-461) on img_inout_dev (values in [-1,1]); the map to [0,1] (:463) is applied exactly when t_lo == 0.
  * cddpm_reverse(t_start) == cddpm_reverse_range(t_start - 1, 0); cutting a chain into consecutive segments gives

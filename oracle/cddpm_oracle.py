@@ -231,7 +231,7 @@ def q_sample(x0: Tensor, t: Tensor, noise: Tensor, buf) -> Tensor:
 
 
 def p_sample(x: Tensor, t: int, cond: Optional[Tensor], sd, buf, z: Optional[Tensor], objective: str = "pred_x0",
-             **unet_kw) -> Tensor:
+             clip_denoised: bool = True, **unet_kw) -> Tensor:
     """One reverse step t -> t-1 (cond_DDPM.py:432-444 -> :422-430 -> :400-420 -> :391-398).
     x0_hat = clamp(model, -1, 1) (pred_x0) or clamp(predict_start_from_noise) (pred_noise);
     mean = coef1[t] x0_hat + coef2[t] x_t; out = mean + exp(0.5 logvar[t]) z, z = 0 at t == 0."""
@@ -239,11 +239,13 @@ def p_sample(x: Tensor, t: int, cond: Optional[Tensor], sd, buf, z: Optional[Ten
     tt = torch.full((b,), t, dtype=torch.long)
     out = unet_forward(x, tt, cond, sd, **unet_kw)
     if objective == "pred_x0":
-        x0 = out.clamp(-1.0, 1.0)
+        x0 = out
     elif objective == "pred_noise":
-        x0 = (buf["sqrt_recip_alphas_cumprod"][t] * x - buf["sqrt_recipm1_alphas_cumprod"][t] * out).clamp(-1.0, 1.0)
+        x0 = buf["sqrt_recip_alphas_cumprod"][t] * x - buf["sqrt_recipm1_alphas_cumprod"][t] * out
     else:
         raise ValueError(f"unknown objective {objective}")
+    if clip_denoised:          # (:416-419 maybe_clip, :426-427)
+        x0 = x0.clamp(-1.0, 1.0)
     mean = buf["posterior_mean_coef1"][t] * x0 + buf["posterior_mean_coef2"][t] * x
     if t > 0:
         return mean + (0.5 * buf["posterior_log_variance_clipped"][t]).exp() * z
@@ -273,7 +275,8 @@ def ddim_time_pairs(num_timesteps: int, sampling_timesteps: int, start_t: int = 
 
 
 def ddim_sample(x_T: Tensor, cond: Optional[Tensor], sd, buf, noises, sampling_timesteps: int, eta: float = 1.0,
-                start_t: int = 0, x_start: Optional[Tensor] = None, objective: str = "pred_x0", **unet_kw) -> Tensor:
+                start_t: int = 0, x_start: Optional[Tensor] = None, objective: str = "pred_x0", clip_denoised: bool = True,
+                **unet_kw) -> Tensor:
     """ddim_sample, Gaussian branch (cond_DDPM.py:466-515). x_T is the N(0,1) draw that is USED (the reference draws one
     more before it and throws it away, :479/:484; with start_t != 0 the used draw is q_sample's noise, :482).
     Per pair: alpha = alphas_cumprod_prev[time], alpha_next = alphas_cumprod_prev[time_next] (:489-490);
@@ -301,7 +304,8 @@ def ddim_sample(x_T: Tensor, cond: Optional[Tensor], sd, buf, noises, sampling_t
                 x0 = buf["sqrt_recip_alphas_cumprod"][time] * img - buf["sqrt_recipm1_alphas_cumprod"][time] * out
             else:
                 raise ValueError(f"unknown objective {objective}")
-            x0 = x0.clamp(-1.0, 1.0)
+            if clip_denoised:
+                x0 = x0.clamp(-1.0, 1.0)
             sigma = eta * ((1 - alpha / alpha_next) * (1 - alpha_next) / (1 - alpha)).sqrt()
             c = ((1 - alpha_next) - sigma ** 2).sqrt()
             z = noises(time).to(dt) if time_next > 0 else 0.0

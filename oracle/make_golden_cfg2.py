@@ -87,7 +87,13 @@ def run_oracle(name, B, H, W, T, fp64):
     else:
         zz = z
     t0 = time.time()
-    out = O.p_sample_loop(xT, cond, sd, buf, zz, start_t=0)
+
+    def zz_progress(t, _zz=zz):
+        if t % 50 == 0:
+            print(f"  oracle {'fp64' if fp64 else 'fp32'} step t={t}  {time.time() - t0:.0f}s", flush=True)
+        return _zz(t)
+
+    out = O.p_sample_loop(xT, cond, sd, buf, zz_progress, start_t=0)
     g = np.load(os.path.join(GOLD, name + ".npz"))
     err = float(np.abs(g["out"].astype(np.float64) - out.numpy().astype(np.float64)).max())
     if fp64:

@@ -1,7 +1,7 @@
 """ORACLE tooling -- build-container only: the `pred_noise` objective (cond_DDPM.py:411-414, :379-383, :612-644) and the
 linear beta schedule (cond_DDPM.py:271-275, :326) on the REFERENCE (imported from /root/reference by ref_harness.py).
 
-    python oracle/make_golden_objectives.py        # ~1 min
+    python oracle/make_golden_objectives.py        # ~1 min        (--only-noclip: just the two clip_denoised=False cases)
 
 Cases (outputs only; inputs are regenerated from seeds by synth.py):
   pn_loop_B2_32x32_T1000_start8    p_sample_loop, objective pred_noise, 8 steps of a T = 1000 cosine chain
@@ -10,6 +10,7 @@ Cases (outputs only; inputs are regenerated from seeds by synth.py):
   pn_ddim_B2_32x32_T1000_S10_eta1  ddim_sample, pred_noise, 10 steps, eta 1
   lin_loop_B2_32x32_T1000_start8   p_sample_loop, pred_x0, beta_schedule 'linear', 8 steps
   lin_schedule_T1000               the 13 buffers of the linear schedule
+  noclip_p_sample_B2_32x32_t5, noclip_ddim_B2_32x32_T1000_S10_eta1     clip_denoised=False (one step / a DDIM chain)
 The manifest records max|oracle - reference| per case.
 """
 from __future__ import annotations
@@ -60,12 +61,52 @@ def loop(sd, name, H, W, B, timesteps, start_t, objective, beta_schedule="cosine
                 oracle_vs_reference_maxabs=float((ref - ora).abs().max()))
 
 
+def noclip_cases(sd, cases):
+    """clip_denoised=False (cond_DDPM.py:433, :467, :416-419, :426-427, :493): one p_sample step at t = 5 and a 10-step
+    DDIM chain, pred_x0; the synthetic UNet's raw prediction leaves [-1,1], so the flag matters (asserted)."""
+    B, H, W, T = 2, 32, 32, 1000
+    _m, diff = build(sd, H, W, T, "pred_x0")
+    cond = torch.from_numpy(synth.synth_cond(SEED_COND, 0, B))
+    x = torch.from_numpy(synth.noise_xT(SEED_XT, 0, B, H, W))
+    z = torch.from_numpy(synth.noise_z(SEED_Z, 5, 0, B, H, W))
+    with R.injected_randn([z]):
+        ref = diff.p_sample(x.clone(), 5, clip_denoised=False, cond=cond)
+    with R.injected_randn([z]):
+        ref_clip = diff.p_sample(x.clone(), 5, clip_denoised=True, cond=cond)
+    assert float((ref - ref_clip).abs().max()) > 1e-3, float((ref - ref_clip).abs().max())
+    ora = O.p_sample(x, 5, cond, sd, O.schedule_buffers(T), z, clip_denoised=False)
+    np.savez_compressed(os.path.join(GOLD, "noclip_p_sample_B2_32x32_t5.npz"), out=ref.numpy())
+    cases["noclip_p_sample_B2_32x32_t5"] = dict(H=H, W=W, B=B, timesteps=T, t=5, clip_denoised=False,
+                                                  oracle_vs_reference_maxabs=float((ref - ora).abs().max()))
+    S, eta = 10, 1.0
+    diff.sampling_timesteps, diff.is_ddim_sampling, diff.ddim_sampling_eta = S, True, eta
+    diff.cfg = types.SimpleNamespace(noisetype="gauss")
+    pairs = O.ddim_time_pairs(T, S, 0)
+    zs = {time: torch.from_numpy(synth.noise_z(SEED_Z, time, 0, B, H, W)) for time, nxt in pairs if nxt > 0}
+    with R.injected_randn([torch.zeros(B, 1, H, W), x] + [zs[time] for time, nxt in pairs if nxt > 0]):
+        ref = diff.ddim_sample((B, 1, H, W), clip_denoised=False, cond=cond, x_start=None, start_t=0)
+    ora = O.ddim_sample(x, cond, sd, O.schedule_buffers(T), lambda t: zs[t], S, eta, 0, None, clip_denoised=False)
+    np.savez_compressed(os.path.join(GOLD, "noclip_ddim_B2_32x32_T1000_S10_eta1.npz"), out=ref.numpy())
+    cases["noclip_ddim_B2_32x32_T1000_S10_eta1"] = dict(H=H, W=W, B=B, timesteps=T, S=S, eta=eta, clip_denoised=False,
+                                                        oracle_vs_reference_maxabs=float((ref - ora).abs().max()))
+    for k in ("noclip_p_sample_B2_32x32_t5", "noclip_ddim_B2_32x32_T1000_S10_eta1"):
+        print(k, cases[k]["oracle_vs_reference_maxabs"], flush=True)
+
+
 def main():
     torch.manual_seed(0)
     sd = O.to_torch_sd(synth.synth_state_dict(SEED_W))
     mpath = os.path.join(GOLD, "MANIFEST.json")
     manifest = json.load(open(mpath))
     cases = manifest["cases"]
+    if "--only-noclip" in sys.argv:
+        noclip_cases(sd, cases)
+        manifest = json.load(open(mpath))          # (another generator may have written meanwhile: merge, do not overwrite)
+        for k in ("noclip_p_sample_B2_32x32_t5", "noclip_ddim_B2_32x32_T1000_S10_eta1"):
+            manifest["cases"][k] = cases[k]
+        json.dump(manifest, open(mpath, "w"), indent=1, sort_keys=True)
+        return
+    noclip_cases(sd, cases)
 
     cases["pn_loop_B2_32x32_T1000_start8"] = loop(sd, "pn_loop_B2_32x32_T1000_start8", 32, 32, 2, 1000, 8, "pred_noise")
     cases["pn_loop_B2_32x32_T50_start0"] = loop(sd, "pn_loop_B2_32x32_T50_start0", 32, 32, 2, 50, 0, "pred_noise")

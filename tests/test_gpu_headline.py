@@ -60,6 +60,9 @@ def test_full_length_chain_vs_reference_golden(eng64, synth):
         assert err < 2 * TOL, report          # states live in [-1, 1] (twice the [0,1] scale of the reconstruction)
     out = eng64.reverse(x, cond, T, noise=nz).cpu().numpy()
     ref = g["out"]
+    dump = os.path.join(os.path.dirname(GOLD), "..", "gpurun_out")
+    if os.path.isdir(dump):                      # kept for offline comparison with the float64 yardstick
+        np.save(os.path.join(dump, NAME + "_hip.npy"), out)
     err = float(np.abs(out - ref).max())
     rms = float(np.sqrt(np.mean((out - ref) ** 2)))
     print("\n".join(report))

@@ -121,3 +121,65 @@ def test_timestep_indices_are_validated(engine_factory, synth):
         eng.q_sample(x.cuda() * 0 + 0.5, 50, x.cuda())
     out = eng.unet_forward(x.cuda(), torch.tensor([0, 49]), cond.cuda())
     assert bool(torch.isfinite(out).all())
+
+
+def test_clip_denoised_false_mirror(engine_factory, sd_np, synth):
+    """p_sample(clip_denoised=False) and ddim_sample(clip_denoised=False) (cond_DDPM.py:433, :467) through the mirror vs the
+    reference's outputs; the engine flag is restored to the default (clipping) afterwards"""
+    U, D = load_pkg("OpenAI_Unet"), load_pkg("cond_DDPM")
+    m = U.UNetModel(image_size=(32, 32), in_channels=1, model_channels=128, out_channels=1, num_res_blocks=3,
+                    attention_resolutions=(3, 6, 12), dropout=0, channel_mult=[1, 2, 2], conv_resample=True, dims=2,
+                    num_classes=128, use_checkpoint=False, use_fp16=True, num_heads=1, num_head_channels=64,
+                    num_heads_upsample=-1, use_scale_shift_norm=True, resblock_updown=True, use_new_attention_order=True,
+                    use_spatial_transformer=False, transformer_depth=1)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()}, strict=True)
+    d = D.GaussianDiffusion(m, image_size=(32, 32), timesteps=1000, sampling_timesteps=1000, objective="pred_x0",
+                            channels=1, loss_type="l1", p2_loss_weight_gamma=0, cfg=None).cuda()
+    B, H, W = 2, 32, 32
+    x, cond = inputs(synth, B, H, W)
+    z = torch.from_numpy(synth.noise_z(3, 5, 0, B, H, W)).cuda()
+    out = d.p_sample(x.cuda(), 5, clip_denoised=False, cond=cond.cuda(), z=z).cpu().numpy()
+    ref = golden("noclip_p_sample_B2_32x32_t5")["out"]
+    assert np.abs(out - ref).max() < TOL
+    clipped = d.p_sample(x.cuda(), 5, cond=cond.cuda(), z=z).cpu().numpy()
+    assert np.abs(clipped - ref).max() > 1e-3
+    d.sampling_timesteps, d.is_ddim_sampling, d.ddim_sampling_eta = 10, True, 1.0
+    zs = {t: torch.from_numpy(synth.noise_z(3, t, 0, B, H, W)).cuda() for t, nxt in d.ddim_time_pairs(0) if nxt > 0}
+    out = d.ddim_sample((B, 1, H, W), clip_denoised=False, cond=cond.cuda(), x_T=x.cuda(), z_noise=zs).cpu().numpy()
+    assert np.abs(out - golden("noclip_ddim_B2_32x32_T1000_S10_eta1")["out"]).max() < TOL
+    out = d.ddim_sample((B, 1, H, W), cond=cond.cuda(), x_T=x.cuda(), z_noise=zs).cpu().numpy()      # default: clipping again
+    assert np.abs(out - golden("ddim_B2_32x32_T1000_S10_eta1")["out"]).max() < TOL
+    m._hip.close()
+
+
+def test_ddim_sample_with_simplex_noise_vs_oracle_composition(sd_np, synth, oracle, sd_torch):
+    """ddim_sample under cfg.noisetype == 'simplex' (cond_DDPM.py:501-503): every pair with time_next > 0 draws a fresh simplex
+    field (the device generator, bit-exact with the reference's for a given numpy seed). Oracle composition: the golden-pinned
+    ddim_sample restatement fed the simplex oracle's fields for the seeds numpy yields in the same order."""
+    import simplex_oracle as SO
+    GN = load_pkg("generate_noise")
+    U, D = load_pkg("OpenAI_Unet"), load_pkg("cond_DDPM")
+    M = load_pkg("DDPM_2D")
+    m = U.UNetModel(image_size=(32, 32), in_channels=1, model_channels=128, out_channels=1, num_res_blocks=3,
+                    attention_resolutions=(3, 6, 12), dropout=0, channel_mult=[1, 2, 2], conv_resample=True, dims=2,
+                    num_classes=128, use_checkpoint=False, use_fp16=True, num_heads=1, num_head_channels=64,
+                    num_heads_upsample=-1, use_scale_shift_norm=True, resblock_updown=True, use_new_attention_order=True,
+                    use_spatial_transformer=False, transformer_depth=1)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()}, strict=True)
+    d = D.GaussianDiffusion(m, image_size=(32, 32), timesteps=1000, sampling_timesteps=6, objective="pred_x0", channels=1,
+                            loss_type="l1", p2_loss_weight_gamma=0, cfg=M.AttrDict(noisetype="simplex")).cuda()
+    B, H, W, S = 2, 32, 32, 6
+    x, cond = inputs(synth, B, H, W)
+    np.random.seed(77)
+    out = d.ddim_sample((B, 1, H, W), cond=cond.cuda(), x_T=x.cuda()).cpu().numpy()
+    np.random.seed(77)
+    fields = {}
+    for time, nxt in oracle.ddim_time_pairs(1000, S, 0):
+        if nxt > 0:
+            GN.draw_seed()
+            fields[time] = torch.from_numpy(SO.gen_noise(GN.draw_seed(), (B, 1, H, W))).float()
+    ref = oracle.ddim_sample(x, cond, sd_torch, oracle.schedule_buffers(1000), lambda t: fields[t], S, 1.0, 0, None).numpy()
+    err = float(np.abs(out - ref).max())
+    print(f"DDIM with simplex noise vs oracle composition: max|delta| {err:.3e}")
+    assert err < TOL and ref.std() > 0.01
+    m._hip.close()
