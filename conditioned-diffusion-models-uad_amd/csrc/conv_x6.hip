@@ -57,12 +57,29 @@ template <> struct SplitT<2> {
     static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 };
 
-#ifdef CDDPM_STAMPS
+#if defined(CDDPM_STAMPS_EPI)
+// accounting of the fixed per-workgroup cost (tools/conv_ab.py, AB_EPI=1): 0 prologue (kernel start .. first chunk), 1 main loop,
+// 2 residual requests, 3 the barrier in front of the epilogue, 4 / 6 transpose of cout half 0 / 1 through LDS, 5 / 7 its stores + statistics
+#define STAMP(i)
+#define FSTAMP(i)
+#define ESTAMP(i) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); st_[i] += now_ - last_; last_ = now_; }
+#elif defined(CDDPM_STAMPS_FINE)
+// finer accounting of the LDS-DMA main loop (tools/conv_ab.py, AB_FINE=1): 0 wait for the chunk's first weight stage and patch
+// registers (vmcnt), 1 the barrier behind it, 2 patch transform + store, 3 the barrier behind it, 4 wait for the next weight stage at
+// the end of a stage (vmcnt), 5 the barrier behind it, 6 request issue + MFMA compute + fold, 7 prologue + epilogue
+#define STAMP(i)
+#define FSTAMP(i) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); st_[i] += now_ - last_; last_ = now_; }
+#define ESTAMP(i)
+#elif defined(CDDPM_STAMPS)
 // phase accounting for diagnostic builds: 0 prologue, 1 patch stage (barrier + transform + split + ds_write), 2 weight
 // stage (ds_write + prefetch issue + barrier), 3 MFMA compute, 4 fold, 5 epilogue
 #define STAMP(i) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); st_[i] += now_ - last_; last_ = now_; }
+#define FSTAMP(i)
+#define ESTAMP(i)
 #else
 #define STAMP(i)
+#define FSTAMP(i)
+#define ESTAMP(i)
 #endif
 
 __device__ __forceinline__ float silu_x6(float v) {
@@ -154,8 +171,8 @@ __global__ __launch_bounds__(64 * ROWS) void conv_split_kernel(const ConvArgs a)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-#ifdef CDDPM_STAMPS
-    unsigned long long st_[6] = {0, 0, 0, 0, 0, 0};
+#if defined(CDDPM_STAMPS) || defined(CDDPM_STAMPS_FINE) || defined(CDDPM_STAMPS_EPI)
+    unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long last_ = __builtin_amdgcn_s_memtime();
     const unsigned long long t0c_ = last_, t0r_ = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -562,10 +579,16 @@ __global__ __launch_bounds__(64 * ROWS) void conv_split_kernel(const ConvArgs a)
     for (int chunk = kc0; chunk < kc1; ++chunk) {
         const bool main_seg = chunk < nch_main;
         const int nst = main_seg ? TAPS / TPS : 1;       // stages of this chunk
+        FSTAMP(chunk == kc0 ? 7 : 6)
+        if (chunk == kc0) { ESTAMP(0) }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this chunk's first weight stage (and its patch registers) have landed
+        FSTAMP(0)
         LOOP_BARRIER();   // ... in every wave, and every wave is done reading the previous patch
+        FSTAMP(1)
         store_act(chunk);
+        FSTAMP(2)
         LOOP_BARRIER();
+        FSTAMP(3)
         STAGGER();
         STAMP(1)
         for (int st = 0; st < nst; ++st) {
@@ -595,8 +618,11 @@ __global__ __launch_bounds__(64 * ROWS) void conv_split_kernel(const ConvArgs a)
                 STAMP(4)
             }
             if (!last_st) {
+                FSTAMP(6)
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                FSTAMP(4)
                 LOOP_BARRIER();   // the next stage has landed in every wave; this stage's buffer is free
+                FSTAMP(5)
                 STAGGER();
             }
         }
@@ -685,6 +711,7 @@ __global__ __launch_bounds__(64 * ROWS) void conv_split_kernel(const ConvArgs a)
     // residual tile of this wave (16 x 16 B per lane): requested here, in one go, so that the loads fly while the waves
     // meet at the barrier and transpose; the accumulator / fragment registers are dead by now. (Loading each batch right
     // before its add exposed the global latency four times per wave: 12 % of the kernel on the +residual layers.)
+    ESTAMP(1)
     v4f rsd_all[2][2][4];
     {
         const int cq = lane & 7, prow = lane >> 3;
@@ -707,7 +734,9 @@ __global__ __launch_bounds__(64 * ROWS) void conv_split_kernel(const ConvArgs a)
                     rsd_all[nt][hb][i] = r;
                 }
     }
+    ESTAMP(2)
     __syncthreads();   // every wave is done with the patch / weight buffers before they become transpose space
+    ESTAMP(3)
     // ---- epilogue: as conv_mfma.hip -- each wave transposes its 64 x 64 tile through a private 8-KB LDS region so
     //      that every lane moves 16 B; bias, residual and the GroupNorm statistics of the output are applied here.
     {
@@ -740,6 +769,7 @@ __global__ __launch_bounds__(64 * ROWS) void conv_split_kernel(const ConvArgs a)
                         tr[(mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * 32 + li] = tot[mt][nt][r];
             }
             __builtin_amdgcn_wave_barrier();
+            if (nt == 0) { ESTAMP(4) } else { ESTAMP(6) }
             const v4f bias = a.bias ? *reinterpret_cast<const v4f*>(a.bias + co) : v4f{0.f, 0.f, 0.f, 0.f};
             const float wsc = (NS == 2) ? a.wscale_inv : 1.0f;      // fp16 weights were pre-scaled by a power of two
             v4f ssum = v4f{0.f, 0.f, 0.f, 0.f}, ssq = ssum;
@@ -783,12 +813,14 @@ __global__ __launch_bounds__(64 * ROWS) void conv_split_kernel(const ConvArgs a)
                 }
             }
             __builtin_amdgcn_wave_barrier();
+            if (nt == 0) { ESTAMP(5) } else { ESTAMP(7) }
         }
     }
-#ifdef CDDPM_STAMPS
+#if defined(CDDPM_STAMPS) || defined(CDDPM_STAMPS_FINE) || defined(CDDPM_STAMPS_EPI)
     STAMP(5)
+    FSTAMP(7)
     if (a.stamps && lane == 0 && wave < 4) {
-        for (int i = 0; i < 6; ++i) atomicAdd(&a.stamps[wave * 8 + i], st_[i]);
+        for (int i = 0; i < 8; ++i) atomicAdd(&a.stamps[wave * 8 + i], st_[i]);
         if (wave == 0) {
             atomicAdd(&a.stamps[40], __builtin_amdgcn_s_memtime() - t0c_);
             atomicAdd(&a.stamps[41], __builtin_amdgcn_s_memrealtime() - t0r_);

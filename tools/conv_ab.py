@@ -33,6 +33,9 @@ SHAPES = [
     ("cat conv1 384>128 @128", 256, 128, 128, 3, 128, 128, 1, 1, 0, 0, 0),
 ]
 PHASES = ["prologue", "patch stage", "weight stage", "mfma compute", "chunk fold", "epilogue"]
+FINE = ["chunk: wait vmcnt", "chunk: barrier A", "patch transform+store", "chunk: barrier B", "stage end: wait vmcnt", "stage end: barrier",
+        "issue + MFMA + fold", "prologue + epilogue"]
+EPI = ["prologue", "main loop", "residual requests", "barrier", "transpose 0", "stores+stats 0", "transpose 1", "stores+stats 1"]
 PHASES8 = ["prologue", "chunk barrier", "patch store", "weight store", "stage barrier", "compute", "fold", "epilogue"]
 
 
@@ -61,7 +64,13 @@ def child(B, iters):
             for g in (0, 1):
                 tt = [st[48 + 4 * g + i] for i in range(4)]
                 row["pp_group%d" % g] = {k: round(v / max(1, sum(tt)), 3) for k, v in zip(("compute", "staging", "wait after compute", "wait after staging"), tt)}
-        if os.environ.get("AB_PHASES8") and sum(st[:16]):
+        if os.environ.get("AB_EPI") and sum(st[:32]):
+            tt = [sum(st[w * 8 + i] for w in range(4)) for i in range(8)]
+            row["fine"] = {p: round(t / max(1, sum(tt)), 4) for p, t in zip(EPI, tt)}
+        elif os.environ.get("AB_FINE") and sum(st[:32]):
+            tt = [sum(st[w * 8 + i] for w in range(4)) for i in range(8)]
+            row["fine"] = {p: round(t / max(1, sum(tt)), 4) for p, t in zip(FINE, tt)}
+        elif os.environ.get("AB_PHASES8") and sum(st[:16]):
             for wv in (0, 1):
                 tt = [st[wv * 8 + i] for i in range(8)]
                 row["wave%d" % (wv * 4)] = {p: round(t / max(1, sum(tt)), 3) for p, t in zip(PHASES8, tt)}
@@ -117,7 +126,7 @@ def main():
                     line += "  " + json.dumps(runs[0][i]["phase_share"])
                 if "clock_GHz" in runs[0][i]:
                     line += f"  clock {runs[0][i]['clock_GHz']} GHz"
-                for wk in ("wave0", "wave4", "pp_group0", "pp_group1", "pp_fine"):
+                for wk in ("fine", "wave0", "wave4", "pp_group0", "pp_group1", "pp_fine"):
                     if wk in runs[0][i]:
                         line += "\n        " + wk + " " + json.dumps(runs[0][i][wk])
                 if "ws_cycles" in runs[0][i]:
