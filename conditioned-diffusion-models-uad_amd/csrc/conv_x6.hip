@@ -288,7 +288,13 @@ __global__ __launch_bounds__(64 * ROWS) void conv_split_kernel(const ConvArgs a)
             areg[k] = v;
         }
     };
-    auto store_act = [&](int chunk) {
+    // The patch of a chunk is produced in two steps so that the arithmetic can run BEFORE the chunk barrier: transform_act turns the
+    // prefetched raw values into their 16-bit split terms in registers (GroupNorm/FiLM affine, SiLU, split: no LDS writes, the
+    // coefficient cache is read-only), write_act stores them to the patch once every wave is done reading the previous one.
+    // A wave that finishes its MFMAs early (the older wave of a SIMD wins the matrix pipe) transforms while its partner still
+    // multiplies, instead of waiting at the barrier and transforming afterwards.
+    typename SplitT<NS>::v4 sreg[NK][NS];
+    auto transform_act = [&](int chunk) {
         const bool main_seg = chunk < nch_main;
         const bool do_silu = main_seg && a.silu;
         v4f cm = v4f{0.f, 0.f, 0.f, 0.f}, ca = v4f{1.f, 1.f, 1.f, 1.f}, cd = cm;
@@ -299,7 +305,6 @@ __global__ __launch_bounds__(64 * ROWS) void conv_split_kernel(const ConvArgs a)
             ca = ldsC[(Cin >> 2) + ci];
             cd = ldsC[2 * (Cin >> 2) + ci];
         }
-        v2f* dst = reinterpret_cast<v2f*>(ldsA);       // 8-B units
 #pragma unroll
         for (int k = 0; k < NK; ++k) {
             v4f v = areg[k];
@@ -311,19 +316,25 @@ __global__ __launch_bounds__(64 * ROWS) void conv_split_kernel(const ConvArgs a)
                     else { v.x = silu_x6(v.x); v.y = silu_x6(v.y); v.z = silu_x6(v.z); v.w = silu_x6(v.w); }
                 }
             }
+            split_x4<NS>(v, sreg[k]);
+        }
+    };
+    auto write_act = [&]() {
+        v2f* dst = reinterpret_cast<v2f*>(ldsA);       // 8-B units
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
             const int q = (tid >> 3) + (THREADS / 8) * k;
             if (q < NPIX) {
-                typename SplitT<NS>::v4 t[NS];
-                split_x4<NS>(v, t);
                 // 4 channels = half a slot: slot u = c4 >> 1 of each split, half c4 & 1
 #pragma unroll
                 for (int sp = 0; sp < NS; ++sp) {
                     const int sl = M16S ? (q * 8 + ((4 * sp + (c4 >> 1)) ^ (int)((colswz >> (3 * k)) & 7u))) : slot_a(q, sp, c4 >> 1);
-                    dst[sl * 2 + (c4 & 1)] = __builtin_bit_cast(v2f, t[sp]);
+                    dst[sl * 2 + (c4 & 1)] = __builtin_bit_cast(v2f, sreg[k][sp]);
                 }
             }
         }
     };
+    auto store_act = [&](int chunk) { transform_act(chunk); write_act(); };
 
     constexpr bool M16 = M16X && (NS == 2);
     typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -583,9 +594,17 @@ __global__ __launch_bounds__(64 * ROWS) void conv_split_kernel(const ConvArgs a)
         if (chunk == kc0) { ESTAMP(0) }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this chunk's first weight stage (and its patch registers) have landed
         FSTAMP(0)
+#ifndef CDDPM_TRANSFORM_AFTER_BARRIER
+        transform_act(chunk);   // registers only: in front of the barrier, where the early waves would otherwise wait
+        FSTAMP(2)
+        LOOP_BARRIER();   // the stage has landed in every wave, and every wave is done reading the previous patch
+        FSTAMP(1)
+        write_act();
+#else
         LOOP_BARRIER();   // ... in every wave, and every wave is done reading the previous patch
         FSTAMP(1)
         store_act(chunk);
+#endif
         FSTAMP(2)
         LOOP_BARRIER();
         FSTAMP(3)
