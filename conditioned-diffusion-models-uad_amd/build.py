@@ -28,7 +28,7 @@ def lib_is_current() -> bool:
     if not os.path.exists(LIB):
         return False
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES + ["kernels.h"]]
+    deps = [os.path.join(CSRC, s) for s in SOURCES + ["kernels.h", "conv_split.h"]]
     deps.append(os.path.join(os.path.dirname(os.path.dirname(CSRC)), "include", "cddpm.h"))
     return all(os.path.getmtime(d) <= t for d in deps if os.path.exists(d))
 

@@ -18,6 +18,14 @@ GOLD = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # The CPU oracle is compared with reference outputs at 2e-6: torch's CPU convolutions sum in an order that depends on the
+    # thread count, so the oracle runs with the thread count the fixtures were generated with (MANIFEST.json "threads": 8),
+    # whatever the host offers (measured: 3 threads move a 50-step chain by 8e-6).
+    try:
+        import torch
+        torch.set_num_threads(8)
+    except Exception:
+        pass
 
 
 def load_pkg(sub: str = ""):
