@@ -268,3 +268,34 @@ def test_config4_sharded_residual_maps_single_rank(eng1000, synth):
         xT = eng1000.noise_fill(cnt, H, W, seed=9, stream_id=synth.STREAM_XT, slice0=s0)
         parts.append((x[s0:s0 + cnt] - eng1000.reverse(xT, cond[s0:s0 + cnt], steps, seed=9, slice0=s0)).abs())
     assert torch.equal(res, torch.cat(parts, 0))
+
+
+@pytest.mark.parametrize("B,H,W", [(1, 4, 4), (3, 12, 20), (2, 8, 44), (5, 36, 28), (2, 4, 132)])
+def test_ragged_geometries_vs_oracle(engine_factory, synth, oracle, sd_torch, B, H, W):
+    """Smallest and ragged image sizes (H, W only need to be multiples of 4: partial 8x32 tiles in every layer, 1x1 images at
+    the deepest level for 4x4, widths beyond one tile), on handles created for exactly that geometry (small-batch split-K plan)
+    and on a larger handle (different plan, partial use of its buffers): UNet forward per block and a 3-step reverse loop."""
+    x, cond = inputs(synth, B, H, W)
+    t = torch.tensor([(37 * i + 5) % 1000 for i in range(B)])
+    taps = {}
+    with torch.no_grad():
+        ref = oracle.unet_forward(x, t, cond, sd_torch, taps=taps)
+    zs = {s: torch.from_numpy(synth.noise_z(3, s, 0, B, H, W)) for s in range(1, 3)}
+    loop_ref = oracle.p_sample_loop(x, cond, sd_torch, oracle.schedule_buffers(1000), lambda s: zs[s], start_t=3).numpy()
+    noise = torch.zeros(3, B, 1, H, W)
+    for s, z in zs.items():
+        noise[s] = z
+    q8 = lambda v: (v + 7) // 8 * 8
+    for (mb, mh, mw) in ((B, H, W), (8, q8(H) + 8, q8(W) + 24)):
+        eng = engine_factory(timesteps=1000, max_batch=mb, max_h=mh, max_w=mw)
+        got = eng.forward_with_taps(x.cuda(), t, cond.cuda())
+        worst = 0.0
+        for name in eng.block_names():
+            r = ref if name == "out" else taps[name]
+            g = got[name].cpu()
+            assert g.shape == r.shape, (name, g.shape, r.shape)
+            worst = max(worst, float((g - r).abs().max()) / (1e-6 + float(r.abs().max())))
+        assert worst < 2e-5, (mb, mh, mw, worst)
+        out = eng.reverse(x.cuda(), cond.cuda(), 3, noise=noise.cuda()).cpu().numpy()
+        assert np.abs(out - loop_ref).max() < TOL, (mb, mh, mw)
+        eng.close()
