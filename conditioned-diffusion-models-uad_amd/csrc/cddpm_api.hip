@@ -1439,6 +1439,72 @@ int cddpm_op_gn_coef(cddpm_handle h, const float* src0, int C0, const float* src
     return 0;
 }
 
+int cddpm_op_conv_dgrad(cddpm_handle h, const float* dy_dev, int Cout, const float* w_host, int Cin, int ksize, float* dx_dev,
+                        int B, int H, int W, void* stream) {
+    if (!h) return -1;
+    const int taps = ksize * ksize;
+    if ((ksize != 1 && ksize != 3) || Cin <= 0 || Cin % 128 || Cout <= 0 || Cout % 32)
+        return fail(h, "cddpm_op_conv_dgrad: unsupported shape (ksize %d, Cin %d must be a multiple of 128, Cout %d of 32)", ksize, Cin, Cout);
+    if (!dy_dev || !w_host || !dx_dev) return fail(h, "cddpm_op_conv_dgrad: NULL argument");
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHECK(h, hipSetDevice(h->device));
+    // wt[ci][co][ky][kx] = w[co][ci][k-1-ky][k-1-kx]: the gradient of a cross-correlation is a cross-correlation with this tensor
+    std::vector<float> wt((size_t)Cin * Cout * taps);
+    for (int co = 0; co < Cout; ++co)
+        for (int ci = 0; ci < Cin; ++ci)
+            for (int t = 0; t < taps; ++t)
+                wt[((size_t)ci * Cout + co) * taps + (taps - 1 - t)] = w_host[((size_t)co * Cin + ci) * taps + t];
+    const int wexp = conv_weight_exp(wt.data(), wt.size());
+    std::vector<float> pk(packed_conv_floats(Cin, Cout, taps));
+    pack_conv_weights(wt.data(), Cin, Cout, taps, pk.data(), wexp);
+    std::vector<float> zb(Cin, 0.f);
+    float *dw = nullptr, *db = nullptr;
+    HIPCHECK(h, hipMalloc((void**)&dw, pk.size() * sizeof(float)));
+    HIPCHECK(h, hipMalloc((void**)&db, (size_t)Cin * sizeof(float)));
+    HIPCHECK(h, hipMemcpy(dw, pk.data(), pk.size() * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHECK(h, hipMemcpy(db, zb.data(), (size_t)Cin * sizeof(float), hipMemcpyHostToDevice));
+    ConvArgs a;
+    zero_conv_args(a);
+    a.src0 = dy_dev; a.C0 = Cout; a.srcH = H; a.srcW = W; a.wpk = dw; a.bias = db;
+    a.wscale_inv = ldexpf(1.0f, -wexp);
+    a.out = dx_dev; a.B = B; a.H = H; a.W = W; a.Cout = Cin; a.taps = taps;
+    launch_conv(a, s);
+    HIPCHECK(h, hipGetLastError());
+    HIPCHECK(h, hipStreamSynchronize(s));
+    (void)hipFree(dw); (void)hipFree(db);
+    return 0;
+}
+
+int cddpm_op_gn_silu_backward(cddpm_handle h, const float* x_dev, const float* da_dev, const float* gamma_host,
+                              const float* beta_host, const float* film_dev, int silu, float* dx_dev, float* dgamma_dev,
+                              float* dbeta_dev, float* dfilm_dev, int B, int HW, int C, void* stream) {
+    if (!h) return -1;
+    if (C % 32 || C <= 0 || C > 1024 || B < 1 || HW < 1) return fail(h, "cddpm_op_gn_silu_backward: unsupported shape (C %d)", C);
+    if (!x_dev || !da_dev || !gamma_host || !beta_host || !dx_dev || !dgamma_dev || !dbeta_dev || (film_dev && !dfilm_dev))
+        return fail(h, "cddpm_op_gn_silu_backward: NULL argument");
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHECK(h, hipSetDevice(h->device));
+    const int ns = gn_nsplit(B, HW);
+    float *rec = nullptr, *g = nullptr, *bt = nullptr, *planes = nullptr, *out_bc = nullptr;
+    double* part = nullptr;
+    HIPCHECK(h, hipMalloc((void**)&rec, (size_t)B * ns * C * 2 * sizeof(float)));
+    HIPCHECK(h, hipMalloc((void**)&g, (size_t)C * sizeof(float)));
+    HIPCHECK(h, hipMalloc((void**)&bt, (size_t)C * sizeof(float)));
+    HIPCHECK(h, hipMalloc((void**)&planes, (size_t)4 * B * C * sizeof(float)));
+    HIPCHECK(h, hipMalloc((void**)&out_bc, (size_t)4 * B * C * sizeof(float)));
+    HIPCHECK(h, hipMalloc((void**)&part, (size_t)B * ns * C * 2 * sizeof(double)));
+    HIPCHECK(h, hipMemcpy(g, gamma_host, (size_t)C * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHECK(h, hipMemcpy(bt, beta_host, (size_t)C * sizeof(float), hipMemcpyHostToDevice));
+    launch_gn_partial(x_dev, C, B, HW, ns, rec, s);
+    launch_gn_bwd_planes(rec, ns, g, bt, film_dev, B, C, HW, planes, s);
+    launch_gn_silu_backward(x_dev, da_dev, planes, g, bt, film_dev, silu, B, C, HW, ns, part, out_bc, dx_dev, dgamma_dev, dbeta_dev,
+                            dfilm_dev, s);
+    HIPCHECK(h, hipGetLastError());
+    HIPCHECK(h, hipStreamSynchronize(s));
+    for (void* p : {(void*)rec, (void*)g, (void*)bt, (void*)planes, (void*)out_bc, (void*)part}) (void)hipFree(p);
+    return 0;
+}
+
 int cddpm_stat_records(int H, int W, int kind) {
     if (H < 1 || W < 1) return -1;
     if (kind == 0) return conv_stat_records(H, W);

@@ -145,6 +145,16 @@ void launch_simplex(unsigned short* out, long long seed, int B, int H, int W, in
                     double frequency, hipStream_t stream);
 
 // ------------------------------------------------------------------------------------------------
+// training pieces (train_kernels.hip): GroupNorm/FiLM/SiLU backward. planes [4][B][C] = mean_g, rstd_g, g', b'; part: fp64 scratch
+// [B][nsplit][C][2]; out_bc [4][B][C] scratch (S1, S2, m1, m2)
+// ------------------------------------------------------------------------------------------------
+void launch_gn_bwd_planes(const float* rec, int nrec, const float* gamma, const float* beta, const float* film, int B, int C, int HW,
+                          float* planes, hipStream_t stream);
+void launch_gn_silu_backward(const float* x, const float* da, const float* planes, const float* gamma, const float* beta,
+                             const float* film, int silu, int B, int C, int HW, int nsplit, double* part, float* out_bc, float* dx,
+                             float* dgamma, float* dbeta, float* dfilm, hipStream_t stream);
+
+// ------------------------------------------------------------------------------------------------
 // attention core (attention.hip): qkv NHWC [B,N,3C] -> out [B,N,C], heads of 64 channels
 // ------------------------------------------------------------------------------------------------
 void launch_attention(const float* qkv, float* out, int B, int N, int C, hipStream_t stream);

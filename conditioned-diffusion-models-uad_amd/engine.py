@@ -382,6 +382,32 @@ class CddpmEngine:
                  "cddpm_op_conv_gn")
         return out, coef
 
+    # ---- training pieces (row f4, kernel level only) ----------------------------------------------------------------
+    def op_conv_dgrad(self, dy, weight):
+        """dL/d(input) of Conv2d(k, padding k // 2): dy NHWC [B,H,W,Cout] on the device, weight the FORWARD tensor [Cout,Cin,k,k]"""
+        B, H, W, Cout = dy.shape
+        wt = np.ascontiguousarray(weight.detach().cpu().numpy(), dtype=np.float32)
+        Cin, k = wt.shape[1], wt.shape[2]
+        dx = torch.empty((B, H, W, Cin), dtype=torch.float32, device=self.device)
+        self._ck(self.lib.cddpm_op_conv_dgrad(self._h, dy.data_ptr(), Cout, wt.ctypes.data, Cin, k, dx.data_ptr(), B, H, W,
+                                              _stream_ptr(self.device)), "cddpm_op_conv_dgrad")
+        return dx
+
+    def op_gn_silu_backward(self, x, da, gamma, beta, film, silu=True):
+        """backward of act(GroupNorm32(x) * (1 + scale) + shift): x, da NHWC [B,H,W,C] -> (dx, dgamma, dbeta, dfilm or None)"""
+        B, H, W, C = x.shape
+        f = lambda t: np.ascontiguousarray(t.detach().cpu().numpy(), dtype=np.float32)
+        g, b = f(gamma), f(beta)
+        dx = torch.empty_like(x)
+        dg = torch.empty((C,), dtype=torch.float32, device=self.device)
+        db = torch.empty((C,), dtype=torch.float32, device=self.device)
+        dfilm = torch.empty((B, 2 * C), dtype=torch.float32, device=self.device) if film is not None else None
+        self._ck(self.lib.cddpm_op_gn_silu_backward(self._h, x.data_ptr(), da.data_ptr(), g.ctypes.data, b.ctypes.data,
+                                                    film.data_ptr() if film is not None else None, int(bool(silu)), dx.data_ptr(),
+                                                    dg.data_ptr(), db.data_ptr(), dfilm.data_ptr() if dfilm is not None else None,
+                                                    B, H * W, C, _stream_ptr(self.device)), "cddpm_op_gn_silu_backward")
+        return dx, dg, db, dfilm
+
     def op_gn_coef(self, src0, src1, gamma, beta, film):
         B = src0.shape[0]
         HW = src0.shape[1] * src0.shape[2]

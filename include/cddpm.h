@@ -242,6 +242,20 @@ int cddpm_op_gn_coef(cddpm_handle h, const float* src0_dev, int C0, const float*
 size_t cddpm_packed_conv_bytes(int Cout, int Cin, int taps);
 int cddpm_pack_conv_weights(const float* w_host, int Cout, int Cin, int taps, void* dst_host, int* scale_exp_out);
 
+/* ---- first pieces of the training step (csrc/train_kernels.hip). Kernel-level entry points only:
+ *      the step itself (src/models/DDPM_2D.py:114-135 -> cond_DDPM.py:565-645 with gradients, Adam, gradient all-reduce) is not built. */
+/* dL/d(input) of Conv2d(k in {1,3}, padding k/2): dx[B,H,W,Cin] = conv_k(dy[B,H,W,Cout], w transposed in (Cout,Cin) and flipped in
+ * (ky,kx)) -- the fused forward convolution kernel on host-repacked weights. w_host is the FORWARD weight [Cout,Cin,k,k];
+ * Cin must be a multiple of 128 and Cout of 32 (true for every convolution inside the UNet). */
+int cddpm_op_conv_dgrad(cddpm_handle h, const float* dy_dev, int Cout, const float* w_host, int Cin, int ksize, float* dx_dev,
+                        int B, int H, int W, void* stream);
+/* backward of a = act(GroupNorm32(x) * (1 + scale) + shift), act = SiLU (silu != 0) or identity (OpenAI_Unet.py:284-338, :325-330):
+ * given da_dev [B,HW,C] writes dx_dev [B,HW,C], dgamma_dev / dbeta_dev [C] and, when film_dev ([B][2C] scale | shift) is given,
+ * dfilm_dev [B][2C]. The forward statistics are recomputed from x_dev. Everything NHWC fp32. */
+int cddpm_op_gn_silu_backward(cddpm_handle h, const float* x_dev, const float* da_dev, const float* gamma_host,
+                              const float* beta_host, const float* film_dev, int silu, float* dx_dev, float* dgamma_dev,
+                              float* dbeta_dev, float* dfilm_dev, int B, int HW, int C, void* stream);
+
 /* GroupNorm statistics record counts per sample for an H x W tensor (host arithmetic, callable without a GPU):
  * kind 0 = records the fused convolution's epilogue writes, 1 = the folded-upsample convolution's, 2 = the stand-alone
  * sweep's pixel-range split. cddpm_create sizes every records buffer for the largest of the three at max_h x max_w, and

@@ -1,0 +1,67 @@
+"""GPU: first kernel-level pieces of the training step (csrc/train_kernels.hip) against torch autograd
+in float64 on the same seeded inputs: conv dgrad (the fused forward convolution on transposed / flipped weights) and the
+GroupNorm32 / FiLM / SiLU backward. The training STEP (src/models/DDPM_2D.py:114-135) is not built: these are its first bricks."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng(engine_factory):
+    return engine_factory(timesteps=50, max_batch=2, max_h=32, max_w=32)
+
+
+def nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous().float().cuda()
+
+
+def nchw(x):
+    return x.permute(0, 3, 1, 2).contiguous().cpu()
+
+
+@pytest.mark.parametrize("Cin,Cout,k,H,W", [(128, 128, 3, 8, 32), (256, 128, 3, 12, 20), (384, 256, 3, 8, 40), (512, 256, 1, 8, 16),
+                                             (128, 32, 3, 8, 32), (256, 768, 1, 8, 8)])
+def test_conv_dgrad_vs_autograd(eng, Cin, Cout, k, H, W):
+    """dL/dx of y = conv2d(x, w, padding = k // 2) for an upstream gradient dy (OpenAI_Unet.py: every Conv2d of a ResBlock,
+    skip_connection, qkv / proj_out as 1x1)"""
+    torch.manual_seed(Cin + Cout + k)
+    B = 2
+    x = torch.randn(B, Cin, H, W, dtype=torch.float64, requires_grad=True)
+    w = torch.randn(Cout, Cin, k, k, dtype=torch.float64) / (Cin * k * k) ** 0.5
+    dy = torch.randn(B, Cout, H, W, dtype=torch.float64)
+    F.conv2d(x, w, None, padding=k // 2).backward(dy)
+    got = nchw(eng.op_conv_dgrad(nhwc(dy), w.float())).double()
+    # same bound as the forward kernel's tests: 2^-20 * sum |dy| |w| per output (+ the fp32 rounding of the float64 weights)
+    lim = 2.0 ** -19 * F.conv2d(dy.abs(), w.abs().transpose(0, 1).flip(2, 3), None, padding=k // 2) + 1e-30
+    err = (got - x.grad).abs()
+    assert float((err / lim).max()) <= 1.0, (float(err.max()), float(x.grad.abs().max()))
+
+
+@pytest.mark.parametrize("C,film,silu", [(128, False, True), (256, True, True), (384, True, True), (256, False, False), (512, True, True)])
+def test_gn_film_silu_backward_vs_autograd(eng, C, film, silu):
+    """a = act(GroupNorm32(x) * (1 + scale) + shift) (OpenAI_Unet.py:284-286 in_layers, :325-330 out_layers with FiLM; the
+    attention block's norm has no activation): dx, dgamma, dbeta, dscale, dshift for an upstream gradient da"""
+    torch.manual_seed(C + int(film) + 2 * int(silu))
+    B, H, W = 2, 12, 20
+    x = (torch.randn(B, C, H, W, dtype=torch.float64) * 1.7 + 0.6).requires_grad_(True)
+    gamma = (1 + 0.1 * torch.randn(C, dtype=torch.float64)).requires_grad_(True)
+    beta = (0.1 * torch.randn(C, dtype=torch.float64)).requires_grad_(True)
+    fl = (0.3 * torch.randn(B, 2 * C, dtype=torch.float64)).requires_grad_(True) if film else None
+    da = torch.randn(B, C, H, W, dtype=torch.float64)
+    u = F.group_norm(x, 32, gamma, beta, eps=1e-5)
+    if film:
+        u = u * (1 + fl[:, :C, None, None]) + fl[:, C:, None, None]
+    a = F.silu(u) if silu else u
+    a.backward(da)
+    dx, dg, db, dfl = eng.op_gn_silu_backward(nhwc(x.detach()), nhwc(da), gamma.detach().float(), beta.detach().float(),
+                                              fl.detach().float().cuda() if film else None, silu=silu)
+    def rel(g, r):
+        return float((g.double().cpu() - r).abs().max() / (r.abs().max() + 1e-12))
+    r = {"dx": rel(nchw(dx), x.grad), "dgamma": rel(dg, gamma.grad), "dbeta": rel(db, beta.grad)}
+    if film:
+        r["dfilm"] = rel(dfl, fl.grad)
+    print(C, film, silu, {k: f"{v:.2e}" for k, v in r.items()})
+    assert max(r.values()) < 2e-5, r
