@@ -1475,6 +1475,24 @@ int cddpm_op_conv_dgrad(cddpm_handle h, const float* dy_dev, int Cout, const flo
     return 0;
 }
 
+int cddpm_op_conv_wgrad(cddpm_handle h, const float* x_dev, const float* coef_dev, int silu, const float* dy_dev, float* dw_dev,
+                        float* db_dev, int B, int H, int W, int Cin, int Cout, void* stream) {
+    if (!h) return -1;
+    if (Cin <= 0 || Cin % 32 || Cout <= 0 || Cout % 64 || H < 4 || H % 4 || W < 1 || B < 1)
+        return fail(h, "cddpm_op_conv_wgrad: unsupported shape (Cin %d multiple of 32, Cout %d of 64, H %d of 4)", Cin, Cout, H);
+    if (!x_dev || !dy_dev || !dw_dev) return fail(h, "cddpm_op_conv_wgrad: NULL argument");
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHECK(h, hipSetDevice(h->device));
+    const int P = conv_wgrad_parts(B, H, W, Cin, Cout);
+    float* part = nullptr;
+    HIPCHECK(h, hipMalloc((void**)&part, (size_t)P * Cout * Cin * 9 * sizeof(float)));
+    launch_conv_wgrad(x_dev, coef_dev, silu, dy_dev, B, H, W, Cin, Cout, part, P, dw_dev, db_dev, s);
+    HIPCHECK(h, hipGetLastError());
+    HIPCHECK(h, hipStreamSynchronize(s));
+    (void)hipFree(part);
+    return 0;
+}
+
 int cddpm_op_gn_silu_backward(cddpm_handle h, const float* x_dev, const float* da_dev, const float* gamma_host,
                               const float* beta_host, const float* film_dev, int silu, float* dx_dev, float* dgamma_dev,
                               float* dbeta_dev, float* dfilm_dev, int B, int HW, int C, void* stream) {

@@ -15,7 +15,9 @@
 //       dx = r_g (du g' - m1 - x^ m2)
 //   Two passes over (x, da): gn_bwd_partial_kernel (per-channel S1, S2 over pixel splits, fp64 inside) and gn_bwd_apply_kernel
 //   (elementwise dx), with gn_bwd_finalize_kernel (tiny) in between. The statistics (mu, r) are an input: the forward's.
-// Not here yet: conv wgrad, attention backward, the embedding MLPs, Adam, the gradient all-reduce.
+// * conv wgrad (below): a pixel-contraction GEMM on the fp32 MFMA with the activation recomputed while staging.
+// Not here yet: attention backward, the one-channel input / output convolutions, the embedding MLPs, the
+// up/down-sampling variants, Adam, the gradient all-reduce, the step's orchestration.
 #include "kernels.h"
 
 namespace cddpm {
@@ -209,6 +211,177 @@ void launch_gn_silu_backward(const float* x, const float* da, const float* plane
     const long long total = (long long)B * HW * (C / 4);
     hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, x, da, planes, out_bc, B, C, HW,
                        silu, dx);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// conv wgrad: dW[co][ci][ky][kx] = sum_{b,y,x} dy[b,y,x,co] * a[b, y + ky - 1, x + kx - 1, ci],  a = act(GroupNorm(x)) recomputed
+// from the conv's input x and the forward's coefficient planes while staging (the activated tensor was never stored).
+//
+// GEMM view: M = Cout, N = 32 input channels x 9 taps, K = pixels. The contraction runs over PIXELS, and both operands are NHWC
+// ([pixel][channel]); the fp32 MFMA v_mfma_f32_32x32x2_f32 takes ONE float per lane for each operand -- lanes 0..31 the 32 rows /
+// columns at k = 0, lanes 32..63 at k = 1 -- so a fragment is one ds_read_b32 of 32 consecutive channels of one pixel (conflict
+// free), a tap is a row offset in the patch, and no transposed image of either tensor is needed; products are exact fp32 (the
+// gradients then carry fp32 accuracy like autograd's; config 5's bf16 autocast can later use the 16-bit pipe the way the forward
+// split kernels do).
+// Workgroup = 4 waves = (32-channel block of the 64 output channels) x (taps 0..4 | 5..8); it walks a contiguous range of
+// 4 x 32-pixel tiles: per tile the dy tile [128 px][64 co] and the activated patch [6 x 34 px][32 ci] go to LDS (59 KB: two
+// workgroups per CU), 64 k-steps of 2 pixels, chains folded per tile into a running total (the three-level accumulation of the
+// forward kernels). P workgroups per (co block, ci chunk) write P partial tiles; wgrad_reduce_kernel adds them in fixed order.
+// ------------------------------------------------------------------------------------------------------------------
+typedef float wg_f32x16 __attribute__((ext_vector_type(16)));
+
+struct WgradArgs {
+    const float* x;        // conv input before the activation, NHWC [B,H,W,Cin]
+    const float* coef;     // [3][B][Cin] (mean, a, d): act input = (x - mean) * a + d, or nullptr
+    int silu;
+    const float* dy;       // NHWC [B,H,W,Cout]
+    int B, H, W, Cin, Cout;
+    float* part;           // [P][Cout/64][Cin/32][64 co][9 taps][32 ci]
+    int P;
+};
+
+__device__ __forceinline__ float silu_t(float v) { return v * sigmoid_t(v); }
+
+__global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a) {
+    constexpr int TR = 4, PW = 34, PH = TR + 2, NPIX = PW * PH;      // tile rows, patch 6 x 34
+    __shared__ float dys[TR * 32 * 64];          // [128 px][64 co]
+    __shared__ float xs[NPIX * 32];              // [204 px][32 ci]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cw = wave & 1, tg = wave >> 1;     // co 32-block, tap group (wave-uniform)
+    const int nchunk = a.Cin >> 5, ncb = a.Cout >> 6;
+    int bid = blockIdx.x;
+    const int chunk = bid % nchunk; bid /= nchunk;
+    const int cb = bid % ncb;
+    const int p = bid / ncb;
+    const int tilesX = (a.W + 31) >> 5, tilesY = a.H / TR;
+    const int ntile = a.B * tilesY * tilesX;
+    const int t0 = (int)((long long)ntile * p / a.P), t1 = (int)((long long)ntile * (p + 1) / a.P);
+    constexpr int NT = 5;                         // taps per wave (group 1 uses 4)
+    const int tapbase = tg * 5, ntap = tg ? 4 : 5;
+    wg_f32x16 acc[NT], tot[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[i][r] = 0.f; tot[i][r] = 0.f; }
+    const int li = lane & 31, lh = lane >> 5;
+    for (int tile = t0; tile < t1; ++tile) {
+        const int tx = tile % tilesX, ty = (tile / tilesX) % tilesY, b = tile / (tilesX * tilesY);
+        const int y0 = ty * TR, x0 = tx * 32;
+        __syncthreads();                          // the previous tile's fragments have been read
+        // dy tile: 128 px x 64 co = 2048 float4
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int e = tid + 256 * i, q = e >> 4, c4 = e & 15;
+            const int y = y0 + (q >> 5), x = x0 + (q & 31);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (x < a.W) v = *reinterpret_cast<const float4*>(a.dy + ((size_t)(b * a.H + y) * a.W + x) * a.Cout + cb * 64 + 4 * c4);
+            *reinterpret_cast<float4*>(dys + q * 64 + 4 * c4) = v;
+        }
+        // activated patch: 204 px x 32 ci = 1632 float4
+        for (int e = tid; e < NPIX * 8; e += 256) {
+            const int q = e >> 3, c4 = e & 7;
+            const int pr = q / PW, pc = q - pr * PW;
+            const int y = y0 + pr - 1, x = x0 + pc - 1;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (y >= 0 && y < a.H && x >= 0 && x < a.W) {
+                v = *reinterpret_cast<const float4*>(a.x + ((size_t)(b * a.H + y) * a.W + x) * a.Cin + chunk * 32 + 4 * c4);
+                if (a.coef) {
+                    const size_t pl = (size_t)a.B * a.Cin, bc = (size_t)b * a.Cin + chunk * 32 + 4 * c4;
+                    const float4 m = *reinterpret_cast<const float4*>(a.coef + bc), g = *reinterpret_cast<const float4*>(a.coef + pl + bc);
+                    const float4 d = *reinterpret_cast<const float4*>(a.coef + 2 * pl + bc);
+                    v.x = (v.x - m.x) * g.x + d.x; v.y = (v.y - m.y) * g.y + d.y; v.z = (v.z - m.z) * g.z + d.z; v.w = (v.w - m.w) * g.w + d.w;
+                }
+                if (a.silu) { v.x = silu_t(v.x); v.y = silu_t(v.y); v.z = silu_t(v.z); v.w = silu_t(v.w); }
+            }
+            *reinterpret_cast<float4*>(xs + q * 32 + 4 * c4) = v;
+        }
+        __syncthreads();
+        // 64 k-steps of two pixels (x, x + 1 of one row); A = dy[px][co], B = act[px + tap][ci]
+#pragma unroll 4
+        for (int k = 0; k < 64; ++k) {
+            const int py = k >> 4, pxx = (k & 15) * 2 + lh;
+            const float av = dys[(py * 32 + pxx) * 64 + cw * 32 + li];
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {
+                if (i < ntap) {
+                    const int t = tapbase + i, ky = t / 3, kx = t - 3 * ky;
+                    const float bv = xs[((py + ky) * PW + pxx + kx) * 32 + li];
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            tot[i] += acc[i];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        }
+    }
+    // partial tile: [64 co][9][32 ci]; D row = co = (r & 3) + 8 (r >> 2) + 4 lh, column = ci = li
+    float* o = a.part + ((((size_t)p * ncb + cb) * nchunk + chunk) * 64) * 9 * 32;
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+        if (i < ntap) {
+            const int t = tapbase + i;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = cw * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                o[((size_t)co * 9 + t) * 32 + li] = tot[i][r];
+            }
+        }
+}
+
+// dW[co][ci][t] (PyTorch layout) = sum over the P partial tiles in the order of p; db[co] = sum of dy over all pixels
+__global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float* __restrict__ part, int P, int Cout, int Cin,
+                                                                float* __restrict__ dw) {
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (long long)Cout * Cin * 9) return;
+    const int t = (int)(e % 9);
+    const int ci = (int)((e / 9) % Cin), co = (int)(e / (9LL * Cin));
+    const int ncb = Cout >> 6, nchunk = Cin >> 5;
+    const size_t tile = (size_t)64 * 9 * 32;
+    const size_t inner = (((size_t)(co >> 6) * nchunk + (ci >> 5)) * 64 + (co & 63)) * 9 * 32 + (size_t)t * 32 + (ci & 31);
+    float s = 0.f;
+    for (int p = 0; p < P; ++p) s += part[(size_t)p * ncb * nchunk * tile + inner];
+    dw[e] = s;
+}
+
+__global__ __launch_bounds__(256) void bias_grad_kernel(const float* __restrict__ dy, long long npix, int Cout, float* __restrict__ db) {
+    // one workgroup per 4-channel quad: fp64 inside, rounded once
+    __shared__ double red[256][5];
+    const int cq = blockIdx.x, tid = threadIdx.x;
+    double s[4] = {0, 0, 0, 0};
+    for (long long p = tid; p < npix; p += 256) {
+        const float4 v = *reinterpret_cast<const float4*>(dy + (size_t)p * Cout + 4 * cq);
+        s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
+    }
+    for (int i = 0; i < 4; ++i) red[tid][i] = s[i];
+    __syncthreads();
+    if (tid < 4) {
+        double t = 0;
+        for (int l = 0; l < 256; ++l) t += red[l][tid];
+        db[4 * cq + tid] = (float)t;
+    }
+}
+
+int conv_wgrad_parts(int B, int H, int W, int Cin, int Cout) {
+    // enough workgroups for two per CU, at most one tile each, at least 1
+    const int ntile = B * (H / 4) * ((W + 31) / 32);
+    const int per = (Cout / 64) * (Cin / 32);
+    int P = (512 + per - 1) / per;
+    if (P > ntile) P = ntile;
+    if (P > 64) P = 64;
+    return P < 1 ? 1 : P;
+}
+
+void launch_conv_wgrad(const float* x, const float* coef, int silu, const float* dy, int B, int H, int W, int Cin, int Cout,
+                       float* part, int P, float* dw, float* db, hipStream_t stream) {
+    WgradArgs a;
+    a.x = x; a.coef = coef; a.silu = silu; a.dy = dy; a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.part = part; a.P = P;
+    hipLaunchKernelGGL(conv_wgrad_kernel, dim3((unsigned)(P * (Cout / 64) * (Cin / 32))), dim3(256), 0, stream, a);
+    const long long n = (long long)Cout * Cin * 9;
+    hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, part, P, Cout, Cin, dw);
+    if (db) hipLaunchKernelGGL(bias_grad_kernel, dim3(Cout / 4), dim3(256), 0, stream, dy, (long long)B * H * W, Cout, db);
 }
 
 }  // namespace cddpm

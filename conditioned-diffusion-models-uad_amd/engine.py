@@ -393,6 +393,17 @@ class CddpmEngine:
                                               _stream_ptr(self.device)), "cddpm_op_conv_dgrad")
         return dx
 
+    def op_conv_wgrad(self, x, coef, silu, dy):
+        """dL/dW [Cout,Cin,3,3] and dL/db [Cout] of y = conv3x3(act(x)) for dy NHWC [B,H,W,Cout]; x NHWC [B,H,W,Cin], coef [3,B,Cin] or None"""
+        B, H, W, Cin = x.shape
+        Cout = dy.shape[-1]
+        dw = torch.empty((Cout, Cin, 3, 3), dtype=torch.float32, device=self.device)
+        db = torch.empty((Cout,), dtype=torch.float32, device=self.device)
+        self._ck(self.lib.cddpm_op_conv_wgrad(self._h, x.data_ptr(), coef.data_ptr() if coef is not None else None, int(bool(silu)),
+                                              dy.data_ptr(), dw.data_ptr(), db.data_ptr(), B, H, W, Cin, Cout,
+                                              _stream_ptr(self.device)), "cddpm_op_conv_wgrad")
+        return dw, db
+
     def op_gn_silu_backward(self, x, da, gamma, beta, film, silu=True):
         """backward of act(GroupNorm32(x) * (1 + scale) + shift): x, da NHWC [B,H,W,C] -> (dx, dgamma, dbeta, dfilm or None)"""
         B, H, W, C = x.shape

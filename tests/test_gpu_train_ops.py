@@ -65,3 +65,26 @@ def test_gn_film_silu_backward_vs_autograd(eng, C, film, silu):
         r["dfilm"] = rel(dfl, fl.grad)
     print(C, film, silu, {k: f"{v:.2e}" for k, v in r.items()})
     assert max(r.values()) < 2e-5, r
+
+
+@pytest.mark.parametrize("Cin,Cout,H,W,act", [(128, 128, 8, 32, True), (256, 128, 12, 20, True), (128, 256, 16, 40, False),
+                                             (384, 128, 8, 64, True), (64, 64, 4, 8, True)])
+def test_conv_wgrad_vs_autograd(eng, Cin, Cout, H, W, act):
+    """dL/dW and dL/db of y = conv2d(act(x), w, b, padding=1), act = SiLU((x - mean) * a + d) with per-(sample, channel)
+    coefficients (what GroupNorm / FiLM fold into; OpenAI_Unet.py:284-338) for an upstream gradient dy"""
+    torch.manual_seed(Cin + Cout + H)
+    B = 2
+    x = torch.randn(B, Cin, H, W, dtype=torch.float64)
+    coef = torch.stack([torch.randn(B, Cin) * 0.2, 1 + 0.2 * torch.randn(B, Cin), torch.randn(B, Cin) * 0.2]).double()
+    a = x
+    if act:
+        a = F.silu((x - coef[0][:, :, None, None]) * coef[1][:, :, None, None] + coef[2][:, :, None, None])
+    w = (torch.randn(Cout, Cin, 3, 3, dtype=torch.float64) / (Cin * 9) ** 0.5).requires_grad_(True)
+    bias = torch.zeros(Cout, dtype=torch.float64, requires_grad=True)
+    dy = torch.randn(B, Cout, H, W, dtype=torch.float64)
+    F.conv2d(a, w, bias, padding=1).backward(dy)
+    dw, db = eng.op_conv_wgrad(nhwc(x), coef.float().cuda() if act else None, act, nhwc(dy))
+    ew = float((dw.double().cpu() - w.grad).abs().max() / w.grad.abs().max())
+    eb = float((db.double().cpu() - bias.grad).abs().max() / bias.grad.abs().max())
+    print(Cin, Cout, H, W, act, f"dW rel {ew:.2e}  db rel {eb:.2e}")
+    assert ew < 1e-5 and eb < 1e-5
