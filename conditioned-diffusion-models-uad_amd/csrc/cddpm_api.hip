@@ -1475,18 +1475,20 @@ int cddpm_op_conv_dgrad(cddpm_handle h, const float* dy_dev, int Cout, const flo
     return 0;
 }
 
-int cddpm_op_conv_wgrad(cddpm_handle h, const float* x_dev, const float* coef_dev, int silu, const float* dy_dev, float* dw_dev,
-                        float* db_dev, int B, int H, int W, int Cin, int Cout, void* stream) {
+int cddpm_op_conv_wgrad(cddpm_handle h, const float* x0_dev, int C0, const float* x1_dev, int C1, const float* coef_dev, int silu,
+                        const float* dy_dev, int Cout, int ksize, float* dw_dev, float* db_dev, int B, int H, int W, void* stream) {
     if (!h) return -1;
-    if (Cin <= 0 || Cin % 32 || Cout <= 0 || Cout % 64 || H < 4 || H % 4 || W < 1 || B < 1)
-        return fail(h, "cddpm_op_conv_wgrad: unsupported shape (Cin %d multiple of 32, Cout %d of 64, H %d of 4)", Cin, Cout, H);
-    if (!x_dev || !dy_dev || !dw_dev) return fail(h, "cddpm_op_conv_wgrad: NULL argument");
+    const int Cin = C0 + C1, taps = ksize * ksize, ck = (ksize == 3) ? 32 : 64;
+    if ((ksize != 1 && ksize != 3) || C0 <= 0 || C1 < 0 || Cin % ck || (C1 > 0 && C0 % 64) || Cout <= 0 || Cout % 64 || H < 4 || H % 4 ||
+        W < 1 || B < 1 || (C1 > 0 && !x1_dev))
+        return fail(h, "cddpm_op_conv_wgrad: unsupported shape (k %d, C0 %d, C1 %d, Cout %d, H %d)", ksize, C0, C1, Cout, H);
+    if (!x0_dev || !dy_dev || !dw_dev) return fail(h, "cddpm_op_conv_wgrad: NULL argument");
     hipStream_t s = (hipStream_t)stream;
     HIPCHECK(h, hipSetDevice(h->device));
-    const int P = conv_wgrad_parts(B, H, W, Cin, Cout);
+    const int P = conv_wgrad_parts(B, H, W, Cin, Cout, taps);
     float* part = nullptr;
-    HIPCHECK(h, hipMalloc((void**)&part, (size_t)P * Cout * Cin * 9 * sizeof(float)));
-    launch_conv_wgrad(x_dev, coef_dev, silu, dy_dev, B, H, W, Cin, Cout, part, P, dw_dev, db_dev, s);
+    HIPCHECK(h, hipMalloc((void**)&part, (size_t)P * Cout * Cin * taps * sizeof(float)));
+    launch_conv_wgrad(x0_dev, C0, x1_dev, C1, coef_dev, silu, dy_dev, B, H, W, Cout, taps, part, P, dw_dev, db_dev, s);
     HIPCHECK(h, hipGetLastError());
     HIPCHECK(h, hipStreamSynchronize(s));
     (void)hipFree(part);

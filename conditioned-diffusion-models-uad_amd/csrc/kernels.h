@@ -150,10 +150,11 @@ void launch_simplex(unsigned short* out, long long seed, int B, int H, int W, in
 // ------------------------------------------------------------------------------------------------
 void launch_gn_bwd_planes(const float* rec, int nrec, const float* gamma, const float* beta, const float* film, int B, int C, int HW,
                           float* planes, hipStream_t stream);
-// conv3x3 wgrad: dw [Cout][Cin][3][3] (PyTorch layout), db [Cout] or nullptr; part: scratch of conv_wgrad_parts() * Cout * Cin * 9 floats
-int conv_wgrad_parts(int B, int H, int W, int Cin, int Cout);
-void launch_conv_wgrad(const float* x, const float* coef, int silu, const float* dy, int B, int H, int W, int Cin, int Cout,
-                       float* part, int P, float* dw, float* db, hipStream_t stream);
+// conv wgrad (3x3 pad 1, or 1x1): dw [Cout][Cin][k][k] (PyTorch layout), db [Cout] or nullptr; input = cat[x0 (C0), x1 (C1)];
+// part: scratch of conv_wgrad_parts() * Cout * Cin * taps floats. Cin multiple of 32 (3x3) / 64 (1x1), C0 of 64, Cout of 64, H of 4
+int conv_wgrad_parts(int B, int H, int W, int Cin, int Cout, int taps);
+void launch_conv_wgrad(const float* x0, int C0, const float* x1, int C1, const float* coef, int silu, const float* dy, int B, int H,
+                       int W, int Cout, int taps, float* part, int P, float* dw, float* db, hipStream_t stream);
 void launch_gn_silu_backward(const float* x, const float* da, const float* planes, const float* gamma, const float* beta,
                              const float* film, int silu, int B, int C, int HW, int nsplit, double* part, float* out_bc, float* dx,
                              float* dgamma, float* dbeta, float* dfilm, hipStream_t stream);

@@ -231,24 +231,33 @@ void launch_gn_silu_backward(const float* x, const float* da, const float* plane
 typedef float wg_f32x16 __attribute__((ext_vector_type(16)));
 
 struct WgradArgs {
-    const float* x;        // conv input before the activation, NHWC [B,H,W,Cin]
-    const float* coef;     // [3][B][Cin] (mean, a, d): act input = (x - mean) * a + d, or nullptr
+    const float* x0; const float* x1;   // conv input before the activation, NHWC [B,H,W,C0] (+ [B,H,W,C1]: channels C0.. of the concatenation)
+    int C0, C1;
+    const float* coef;     // [3][B][Cin] (mean, a, d) over the concatenated channels: act input = (x - mean) * a + d, or nullptr
     int silu;
     const float* dy;       // NHWC [B,H,W,Cout]
-    int B, H, W, Cin, Cout;
-    float* part;           // [P][Cout/64][Cin/32][64 co][9 taps][32 ci]
+    int B, H, W, Cout;
+    float* part;           // [P][Cout/64][Cin/CK][64 co][TAPS][CK ci]
     int P;
 };
 
 __device__ __forceinline__ float silu_t(float v) { return v * sigmoid_t(v); }
 
+// TAPS = 9: 3x3, padding 1, 32 input channels per workgroup, wave = (co 32-block, taps 0..4 | 5..8)
+// TAPS = 1: 1x1 (skip_connection, qkv, proj_out), 64 input channels per workgroup, wave = (co 32-block, ci 32-block)
+template <int TAPS>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a) {
-    constexpr int TR = 4, PW = 34, PH = TR + 2, NPIX = PW * PH;      // tile rows, patch 6 x 34
-    __shared__ float dys[TR * 32 * 64];          // [128 px][64 co]
-    __shared__ float xs[NPIX * 32];              // [204 px][32 ci]
+    constexpr int TR = 4;                                   // tile rows
+    constexpr int PAD = (TAPS == 9) ? 1 : 0;
+    constexpr int PW = 32 + 2 * PAD, PH = TR + 2 * PAD, NPIX = PW * PH;
+    constexpr int CK = (TAPS == 9) ? 32 : 64;               // input channels per workgroup
+    constexpr int NT = (TAPS == 9) ? 5 : 1;                 // accumulators per wave
+    __shared__ float dys[TR * 32 * 64];                     // [128 px][64 co]
+    __shared__ float xs[NPIX * CK];                         // [204 px][32 ci] | [128 px][64 ci]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int cw = wave & 1, tg = wave >> 1;     // co 32-block, tap group (wave-uniform)
-    const int nchunk = a.Cin >> 5, ncb = a.Cout >> 6;
+    const int cw = wave & 1, tg = wave >> 1;                // co 32-block; tap group | ci 32-block (wave-uniform)
+    const int Cin = a.C0 + a.C1;
+    const int nchunk = Cin / CK, ncb = a.Cout >> 6;
     int bid = blockIdx.x;
     const int chunk = bid % nchunk; bid /= nchunk;
     const int cb = bid % ncb;
@@ -256,8 +265,11 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a) {
     const int tilesX = (a.W + 31) >> 5, tilesY = a.H / TR;
     const int ntile = a.B * tilesY * tilesX;
     const int t0 = (int)((long long)ntile * p / a.P), t1 = (int)((long long)ntile * (p + 1) / a.P);
-    constexpr int NT = 5;                         // taps per wave (group 1 uses 4)
-    const int tapbase = tg * 5, ntap = tg ? 4 : 5;
+    const int tapbase = (TAPS == 9) ? tg * 5 : 0, ntap = (TAPS == 9) ? (tg ? 4 : 5) : 1;
+    // source tensor of this chunk (a chunk never straddles the two sources: C0 is a multiple of 64)
+    const int ch0 = chunk * CK;
+    const float* xsrc = (ch0 < a.C0) ? a.x0 : a.x1;
+    const int Cs = (ch0 < a.C0) ? a.C0 : a.C1, cs0 = (ch0 < a.C0) ? ch0 : ch0 - a.C0;
     wg_f32x16 acc[NT], tot[NT];
 #pragma unroll
     for (int i = 0; i < NT; ++i)
@@ -277,23 +289,23 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a) {
             if (x < a.W) v = *reinterpret_cast<const float4*>(a.dy + ((size_t)(b * a.H + y) * a.W + x) * a.Cout + cb * 64 + 4 * c4);
             *reinterpret_cast<float4*>(dys + q * 64 + 4 * c4) = v;
         }
-        // activated patch: 204 px x 32 ci = 1632 float4
-        for (int e = tid; e < NPIX * 8; e += 256) {
-            const int q = e >> 3, c4 = e & 7;
+        // activated patch: NPIX px x CK ci
+        for (int e = tid; e < NPIX * (CK / 4); e += 256) {
+            const int q = e / (CK / 4), c4 = e % (CK / 4);
             const int pr = q / PW, pc = q - pr * PW;
-            const int y = y0 + pr - 1, x = x0 + pc - 1;
+            const int y = y0 + pr - PAD, x = x0 + pc - PAD;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (y >= 0 && y < a.H && x >= 0 && x < a.W) {
-                v = *reinterpret_cast<const float4*>(a.x + ((size_t)(b * a.H + y) * a.W + x) * a.Cin + chunk * 32 + 4 * c4);
+                v = *reinterpret_cast<const float4*>(xsrc + ((size_t)(b * a.H + y) * a.W + x) * Cs + cs0 + 4 * c4);
                 if (a.coef) {
-                    const size_t pl = (size_t)a.B * a.Cin, bc = (size_t)b * a.Cin + chunk * 32 + 4 * c4;
+                    const size_t pl = (size_t)a.B * Cin, bc = (size_t)b * Cin + ch0 + 4 * c4;
                     const float4 m = *reinterpret_cast<const float4*>(a.coef + bc), g = *reinterpret_cast<const float4*>(a.coef + pl + bc);
                     const float4 d = *reinterpret_cast<const float4*>(a.coef + 2 * pl + bc);
                     v.x = (v.x - m.x) * g.x + d.x; v.y = (v.y - m.y) * g.y + d.y; v.z = (v.z - m.z) * g.z + d.z; v.w = (v.w - m.w) * g.w + d.w;
                 }
                 if (a.silu) { v.x = silu_t(v.x); v.y = silu_t(v.y); v.z = silu_t(v.z); v.w = silu_t(v.w); }
             }
-            *reinterpret_cast<float4*>(xs + q * 32 + 4 * c4) = v;
+            *reinterpret_cast<float4*>(xs + q * CK + 4 * c4) = v;
         }
         __syncthreads();
         // 64 k-steps of two pixels (x, x + 1 of one row); A = dy[px][co], B = act[px + tap][ci]
@@ -304,8 +316,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a) {
 #pragma unroll
             for (int i = 0; i < NT; ++i) {
                 if (i < ntap) {
-                    const int t = tapbase + i, ky = t / 3, kx = t - 3 * ky;
-                    const float bv = xs[((py + ky) * PW + pxx + kx) * 32 + li];
+                    const int t = tapbase + i, ky = (TAPS == 9) ? t / 3 : 0, kx = (TAPS == 9) ? t - 3 * ky : 0;
+                    const float bv = xs[((py + ky) * PW + pxx + kx) * CK + ((TAPS == 9) ? 0 : tg * 32) + li];
                     acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i], 0, 0, 0);
                 }
             }
@@ -317,8 +329,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a) {
             for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
         }
     }
-    // partial tile: [64 co][9][32 ci]; D row = co = (r & 3) + 8 (r >> 2) + 4 lh, column = ci = li
-    float* o = a.part + ((((size_t)p * ncb + cb) * nchunk + chunk) * 64) * 9 * 32;
+    // partial tile: [64 co][TAPS][CK ci]; D row = co = (r & 3) + 8 (r >> 2) + 4 lh, column = ci = li
+    float* o = a.part + ((((size_t)p * ncb + cb) * nchunk + chunk) * 64) * TAPS * CK;
 #pragma unroll
     for (int i = 0; i < NT; ++i)
         if (i < ntap) {
@@ -326,21 +338,22 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = cw * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                o[((size_t)co * 9 + t) * 32 + li] = tot[i][r];
+                o[((size_t)co * TAPS + t) * CK + ((TAPS == 9) ? 0 : tg * 32) + li] = tot[i][r];
             }
         }
 }
 
-// dW[co][ci][t] (PyTorch layout) = sum over the P partial tiles in the order of p; db[co] = sum of dy over all pixels
-__global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float* __restrict__ part, int P, int Cout, int Cin,
+// dW[co][ci][t] (PyTorch layout) = sum over the P partial tiles in the order of p
+__global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float* __restrict__ part, int P, int Cout, int Cin, int taps,
                                                                 float* __restrict__ dw) {
     const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (e >= (long long)Cout * Cin * 9) return;
-    const int t = (int)(e % 9);
-    const int ci = (int)((e / 9) % Cin), co = (int)(e / (9LL * Cin));
-    const int ncb = Cout >> 6, nchunk = Cin >> 5;
-    const size_t tile = (size_t)64 * 9 * 32;
-    const size_t inner = (((size_t)(co >> 6) * nchunk + (ci >> 5)) * 64 + (co & 63)) * 9 * 32 + (size_t)t * 32 + (ci & 31);
+    if (e >= (long long)Cout * Cin * taps) return;
+    const int CK = (taps == 9) ? 32 : 64;
+    const int t = (int)(e % taps);
+    const int ci = (int)((e / taps) % Cin), co = (int)(e / ((long long)taps * Cin));
+    const int ncb = Cout >> 6, nchunk = Cin / CK;
+    const size_t tile = (size_t)64 * taps * CK;
+    const size_t inner = (((size_t)(co >> 6) * nchunk + ci / CK) * 64 + (co & 63)) * taps * CK + (size_t)t * CK + (ci % CK);
     float s = 0.f;
     for (int p = 0; p < P; ++p) s += part[(size_t)p * ncb * nchunk * tile + inner];
     dw[e] = s;
@@ -364,23 +377,27 @@ __global__ __launch_bounds__(256) void bias_grad_kernel(const float* __restrict_
     }
 }
 
-int conv_wgrad_parts(int B, int H, int W, int Cin, int Cout) {
+int conv_wgrad_parts(int B, int H, int W, int Cin, int Cout, int taps) {
     // enough workgroups for two per CU, at most one tile each, at least 1
     const int ntile = B * (H / 4) * ((W + 31) / 32);
-    const int per = (Cout / 64) * (Cin / 32);
+    const int per = (Cout / 64) * (Cin / (taps == 9 ? 32 : 64));
     int P = (512 + per - 1) / per;
     if (P > ntile) P = ntile;
     if (P > 64) P = 64;
     return P < 1 ? 1 : P;
 }
 
-void launch_conv_wgrad(const float* x, const float* coef, int silu, const float* dy, int B, int H, int W, int Cin, int Cout,
-                       float* part, int P, float* dw, float* db, hipStream_t stream) {
+void launch_conv_wgrad(const float* x0, int C0, const float* x1, int C1, const float* coef, int silu, const float* dy, int B, int H,
+                       int W, int Cout, int taps, float* part, int P, float* dw, float* db, hipStream_t stream) {
     WgradArgs a;
-    a.x = x; a.coef = coef; a.silu = silu; a.dy = dy; a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.part = part; a.P = P;
-    hipLaunchKernelGGL(conv_wgrad_kernel, dim3((unsigned)(P * (Cout / 64) * (Cin / 32))), dim3(256), 0, stream, a);
-    const long long n = (long long)Cout * Cin * 9;
-    hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, part, P, Cout, Cin, dw);
+    a.x0 = x0; a.x1 = x1; a.C0 = C0; a.C1 = C1; a.coef = coef; a.silu = silu; a.dy = dy; a.B = B; a.H = H; a.W = W; a.Cout = Cout;
+    a.part = part; a.P = P;
+    const int Cin = C0 + C1;
+    const unsigned grid = (unsigned)(P * (Cout / 64) * (Cin / (taps == 9 ? 32 : 64)));
+    if (taps == 9) hipLaunchKernelGGL(conv_wgrad_kernel<9>, dim3(grid), dim3(256), 0, stream, a);
+    else           hipLaunchKernelGGL(conv_wgrad_kernel<1>, dim3(grid), dim3(256), 0, stream, a);
+    const long long n = (long long)Cout * Cin * taps;
+    hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, part, P, Cout, Cin, taps, dw);
     if (db) hipLaunchKernelGGL(bias_grad_kernel, dim3(Cout / 4), dim3(256), 0, stream, dy, (long long)B * H * W, Cout, db);
 }
 

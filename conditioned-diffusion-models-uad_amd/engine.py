@@ -393,15 +393,16 @@ class CddpmEngine:
                                               _stream_ptr(self.device)), "cddpm_op_conv_dgrad")
         return dx
 
-    def op_conv_wgrad(self, x, coef, silu, dy):
-        """dL/dW [Cout,Cin,3,3] and dL/db [Cout] of y = conv3x3(act(x)) for dy NHWC [B,H,W,Cout]; x NHWC [B,H,W,Cin], coef [3,B,Cin] or None"""
-        B, H, W, Cin = x.shape
+    def op_conv_wgrad(self, x0, x1, coef, silu, dy, ksize=3):
+        """dL/dW [Cout,Cin,k,k] and dL/db [Cout] of y = conv_k(act(cat[x0, x1])) for dy NHWC [B,H,W,Cout]; x0 / x1 NHWC, coef [3,B,Cin] or None"""
+        B, H, W, C0 = x0.shape
+        C1 = x1.shape[-1] if x1 is not None else 0
         Cout = dy.shape[-1]
-        dw = torch.empty((Cout, Cin, 3, 3), dtype=torch.float32, device=self.device)
+        dw = torch.empty((Cout, C0 + C1, ksize, ksize), dtype=torch.float32, device=self.device)
         db = torch.empty((Cout,), dtype=torch.float32, device=self.device)
-        self._ck(self.lib.cddpm_op_conv_wgrad(self._h, x.data_ptr(), coef.data_ptr() if coef is not None else None, int(bool(silu)),
-                                              dy.data_ptr(), dw.data_ptr(), db.data_ptr(), B, H, W, Cin, Cout,
-                                              _stream_ptr(self.device)), "cddpm_op_conv_wgrad")
+        self._ck(self.lib.cddpm_op_conv_wgrad(self._h, x0.data_ptr(), C0, x1.data_ptr() if x1 is not None else None, C1,
+                                              coef.data_ptr() if coef is not None else None, int(bool(silu)), dy.data_ptr(), Cout, ksize,
+                                              dw.data_ptr(), db.data_ptr(), B, H, W, _stream_ptr(self.device)), "cddpm_op_conv_wgrad")
         return dw, db
 
     def op_gn_silu_backward(self, x, da, gamma, beta, film, silu=True):

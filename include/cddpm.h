@@ -249,11 +249,12 @@ int cddpm_pack_conv_weights(const float* w_host, int Cout, int Cin, int taps, vo
  * Cin must be a multiple of 128 and Cout of 32 (true for every convolution inside the UNet). */
 int cddpm_op_conv_dgrad(cddpm_handle h, const float* dy_dev, int Cout, const float* w_host, int Cin, int ksize, float* dx_dev,
                         int B, int H, int W, void* stream);
-/* dL/d(weight), dL/d(bias) of y = Conv2d 3x3 (padding 1) applied to a = act(x) with act(v) = silu?((v - mean) * a + d) as in
- * cddpm_op_conv (coef_dev [3][B][Cin] or NULL): dw_dev [Cout,Cin,3,3] (PyTorch layout) = sum over batch and pixels of dy (x) a,
- * db_dev [Cout] = sum of dy (may be NULL). x_dev [B,H,W,Cin], dy_dev [B,H,W,Cout]; Cin multiple of 32, Cout of 64, H of 4. */
-int cddpm_op_conv_wgrad(cddpm_handle h, const float* x_dev, const float* coef_dev, int silu, const float* dy_dev, float* dw_dev,
-                        float* db_dev, int B, int H, int W, int Cin, int Cout, void* stream);
+/* dL/d(weight), dL/d(bias) of y = Conv2d(k in {1,3}, padding k/2) applied to a = act(cat[x0, x1]) with act(v) = silu?((v - mean) *
+ * a + d) as in cddpm_op_conv (coef_dev [3][B][C0 + C1] or NULL): dw_dev [Cout,Cin,k,k] (PyTorch layout) = sum over batch and pixels of
+ * dy (x) a, db_dev [Cout] = sum of dy (may be NULL). x0_dev [B,H,W,C0], x1_dev [B,H,W,C1] or NULL (C1 = 0), dy_dev [B,H,W,Cout];
+ * C0 + C1 a multiple of 32 (k = 3) or 64 (k = 1), C0 a multiple of 64 when C1 > 0, Cout of 64, H of 4. */
+int cddpm_op_conv_wgrad(cddpm_handle h, const float* x0_dev, int C0, const float* x1_dev, int C1, const float* coef_dev, int silu,
+                        const float* dy_dev, int Cout, int ksize, float* dw_dev, float* db_dev, int B, int H, int W, void* stream);
 /* backward of a = act(GroupNorm32(x) * (1 + scale) + shift), act = SiLU (silu != 0) or identity (OpenAI_Unet.py:284-338, :325-330):
  * given da_dev [B,HW,C] writes dx_dev [B,HW,C], dgamma_dev / dbeta_dev [C] and, when film_dev ([B][2C] scale | shift) is given,
  * dfilm_dev [B][2C]. The forward statistics are recomputed from x_dev. Everything NHWC fp32. */

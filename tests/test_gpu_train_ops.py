@@ -67,24 +67,29 @@ def test_gn_film_silu_backward_vs_autograd(eng, C, film, silu):
     assert max(r.values()) < 2e-5, r
 
 
-@pytest.mark.parametrize("Cin,Cout,H,W,act", [(128, 128, 8, 32, True), (256, 128, 12, 20, True), (128, 256, 16, 40, False),
-                                             (384, 128, 8, 64, True), (64, 64, 4, 8, True)])
-def test_conv_wgrad_vs_autograd(eng, Cin, Cout, H, W, act):
-    """dL/dW and dL/db of y = conv2d(act(x), w, b, padding=1), act = SiLU((x - mean) * a + d) with per-(sample, channel)
-    coefficients (what GroupNorm / FiLM fold into; OpenAI_Unet.py:284-338) for an upstream gradient dy"""
-    torch.manual_seed(Cin + Cout + H)
-    B = 2
+@pytest.mark.parametrize("C0,C1,Cout,k,H,W,act", [(128, 0, 128, 3, 8, 32, True), (256, 0, 128, 3, 12, 20, True), (128, 0, 256, 3, 16, 40, False),
+                                                  (256, 128, 128, 3, 8, 64, True), (64, 0, 64, 3, 4, 8, True), (256, 256, 256, 3, 8, 8, True),
+                                                  (256, 0, 768, 1, 8, 8, True), (256, 256, 256, 1, 8, 16, False), (128, 0, 256, 1, 12, 36, False)])
+def test_conv_wgrad_vs_autograd(eng, C0, C1, Cout, k, H, W, act):
+    """dL/dW and dL/db of y = conv2d(act(cat[x0, x1]), w, b, padding = k // 2), act = [SiLU]((x - mean) * a + d) with per-(sample,
+    channel) coefficients (what GroupNorm / FiLM fold into; OpenAI_Unet.py:284-338; the output path concatenates a skip tensor,
+    :948; 1x1: skip_connection on the raw input, qkv behind a GroupNorm without activation, proj_out) for an upstream gradient dy"""
+    torch.manual_seed(C0 + C1 + Cout + H + k)
+    B, Cin = 2, C0 + C1
     x = torch.randn(B, Cin, H, W, dtype=torch.float64)
     coef = torch.stack([torch.randn(B, Cin) * 0.2, 1 + 0.2 * torch.randn(B, Cin), torch.randn(B, Cin) * 0.2]).double()
     a = x
     if act:
-        a = F.silu((x - coef[0][:, :, None, None]) * coef[1][:, :, None, None] + coef[2][:, :, None, None])
-    w = (torch.randn(Cout, Cin, 3, 3, dtype=torch.float64) / (Cin * 9) ** 0.5).requires_grad_(True)
+        a = (x - coef[0][:, :, None, None]) * coef[1][:, :, None, None] + coef[2][:, :, None, None]
+        if k == 3:
+            a = F.silu(a)
+    w = (torch.randn(Cout, Cin, k, k, dtype=torch.float64) / (Cin * k * k) ** 0.5).requires_grad_(True)
     bias = torch.zeros(Cout, dtype=torch.float64, requires_grad=True)
     dy = torch.randn(B, Cout, H, W, dtype=torch.float64)
-    F.conv2d(a, w, bias, padding=1).backward(dy)
-    dw, db = eng.op_conv_wgrad(nhwc(x), coef.float().cuda() if act else None, act, nhwc(dy))
+    F.conv2d(a, w, bias, padding=k // 2).backward(dy)
+    dw, db = eng.op_conv_wgrad(nhwc(x[:, :C0]), nhwc(x[:, C0:]) if C1 else None, coef.float().cuda() if act else None, act and k == 3,
+                               nhwc(dy), ksize=k)
     ew = float((dw.double().cpu() - w.grad).abs().max() / w.grad.abs().max())
     eb = float((db.double().cpu() - bias.grad).abs().max() / bias.grad.abs().max())
-    print(Cin, Cout, H, W, act, f"dW rel {ew:.2e}  db rel {eb:.2e}")
+    print(C0, C1, Cout, k, H, W, act, f"dW rel {ew:.2e}  db rel {eb:.2e}")
     assert ew < 1e-5 and eb < 1e-5
