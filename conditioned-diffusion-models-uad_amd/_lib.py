@@ -79,6 +79,8 @@ SYMBOLS = {
     "cddpm_encoder_forward": (_i, [_vp, _fp, _fp, _i, _i, _i, _vp]),
     "cddpm_op_conv_dgrad": (_i, [_vp, _fp, _i, _fp, _i, _i, _fp, _i, _i, _i, _vp]),
     "cddpm_op_conv_wgrad": (_i, [_vp, _fp, _i, _fp, _i, _fp, _i, _fp, _i, _i, _fp, _fp, _i, _i, _i, _vp]),
+    "cddpm_op_attention_backward": (_i, [_vp, _fp, _fp, _fp, _i, _i, _i, _vp]),
+    "cddpm_op_linear_backward": (_i, [_vp, _fp, _fp, _fp, _i, _i, _i, _i, _fp, _fp, _fp, _vp]),
     "cddpm_op_gn_silu_backward": (_i, [_vp, _fp, _fp, _fp, _fp, _fp, _i, _fp, _fp, _fp, _fp, _i, _i, _i, _vp]),
     "cddpm_stat_records": (_i, [_i, _i, _i]),
     "cddpm_packed_conv_bytes": (_sz, [_i, _i, _i]),

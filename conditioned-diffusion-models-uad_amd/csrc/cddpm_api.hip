@@ -1495,6 +1495,39 @@ int cddpm_op_conv_wgrad(cddpm_handle h, const float* x0_dev, int C0, const float
     return 0;
 }
 
+int cddpm_op_attention_backward(cddpm_handle h, const float* qkv_dev, const float* da_dev, float* dqkv_dev, int B, int N, int C,
+                                void* stream) {
+    if (!h) return -1;
+    if (C <= 0 || C % 64 || N < 1 || B < 1) return fail(h, "cddpm_op_attention_backward: C must be a multiple of 64");
+    if (!qkv_dev || !da_dev || !dqkv_dev) return fail(h, "cddpm_op_attention_backward: NULL argument");
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHECK(h, hipSetDevice(h->device));
+    const size_t nn = (size_t)B * (C / 64) * N * N;
+    float *p = nullptr, *dp = nullptr;
+    HIPCHECK(h, hipMalloc((void**)&p, nn * sizeof(float)));
+    HIPCHECK(h, hipMalloc((void**)&dp, nn * sizeof(float)));
+    launch_attention_backward(qkv_dev, da_dev, dqkv_dev, p, dp, B, N, C, s);
+    HIPCHECK(h, hipGetLastError());
+    HIPCHECK(h, hipStreamSynchronize(s));
+    (void)hipFree(p); (void)hipFree(dp);
+    return 0;
+}
+
+int cddpm_op_linear_backward(cddpm_handle h, const float* x_dev, const float* w_dev, const float* dy_dev, int M, int N, int K,
+                             int silu_in, float* dw_dev, float* db_dev, float* dx_dev, void* stream) {
+    if (!h) return -1;
+    if (M < 1 || N < 1 || K < 1 || !x_dev || !w_dev || !dy_dev || !dw_dev) return fail(h, "cddpm_op_linear_backward: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHECK(h, hipSetDevice(h->device));
+    float* a = nullptr;
+    if (silu_in) HIPCHECK(h, hipMalloc((void**)&a, (size_t)M * K * sizeof(float)));
+    launch_linear_backward(x_dev, w_dev, dy_dev, M, N, K, silu_in, a, dw_dev, db_dev, dx_dev, s);
+    HIPCHECK(h, hipGetLastError());
+    HIPCHECK(h, hipStreamSynchronize(s));
+    if (a) (void)hipFree(a);
+    return 0;
+}
+
 int cddpm_op_gn_silu_backward(cddpm_handle h, const float* x_dev, const float* da_dev, const float* gamma_host,
                               const float* beta_host, const float* film_dev, int silu, float* dx_dev, float* dgamma_dev,
                               float* dbeta_dev, float* dfilm_dev, int B, int HW, int C, void* stream) {

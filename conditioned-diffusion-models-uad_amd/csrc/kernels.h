@@ -155,6 +155,13 @@ void launch_gn_bwd_planes(const float* rec, int nrec, const float* gamma, const 
 int conv_wgrad_parts(int B, int H, int W, int Cin, int Cout, int taps);
 void launch_conv_wgrad(const float* x0, int C0, const float* x1, int C1, const float* coef, int silu, const float* dy, int B, int H,
                        int W, int Cout, int taps, float* part, int P, float* dw, float* db, hipStream_t stream);
+// QKVAttention backward: qkv [B][N][3C] (q | k | v), da [B][N][C] -> dqkv [B][N][3C]; p, dp: scratch [B * C / 64][N][N] floats each
+void launch_attention_backward(const float* qkv, const float* da, float* dqkv, float* p, float* dp, int B, int N, int C,
+                               hipStream_t stream);
+// backward of y = [SiLU](x) W^T + b: x [M][K], W [N][K], dy [M][N] -> dW [N][K], db [N] (or nullptr), dx [M][K] (or nullptr);
+// a_scratch [M][K] when silu_in
+void launch_linear_backward(const float* x, const float* W, const float* dy, int M, int N, int K, int silu_in, float* a_scratch,
+                            float* dW, float* db, float* dx, hipStream_t stream);
 void launch_gn_silu_backward(const float* x, const float* da, const float* planes, const float* gamma, const float* beta,
                              const float* film, int silu, int B, int C, int HW, int nsplit, double* part, float* out_bc, float* dx,
                              float* dgamma, float* dbeta, float* dfilm, hipStream_t stream);

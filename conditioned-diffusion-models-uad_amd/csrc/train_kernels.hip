@@ -401,4 +401,194 @@ void launch_conv_wgrad(const float* x0, int C0, const float* x1, int C1, const f
     if (db) hipLaunchKernelGGL(bias_grad_kernel, dim3(Cout / 4), dim3(256), 0, stream, dy, (long long)B * H * W, Cout, db);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Batched fp32 GEMM on v_mfma_f32_32x32x2_f32 (exact fp32 products): C[z] = alpha * op(A[z]) . op(B[z]), arbitrary M, N, K and
+// strides, two-level batch index z = (z0, z1). Used by the attention backward (five N x N x 64 products per head) and by the
+// backward of the embedding linears. 64 x 64 tiles, 4 waves (2 x 2 of 32 x 32), K steps of 32 through k-major LDS tiles
+// (operand fragment = one ds_read_b32 of 32 consecutive rows / columns at one k). Correctness-first: these products are < 2 % of a
+// training step's FLOPs.
+// ------------------------------------------------------------------------------------------------------------------
+struct GemmArgs {
+    const float* A; const float* B; float* C;
+    int M, N, K;
+    long long lda, ldb, ldc;          // row strides of the STORED matrices
+    int transA, transB;               // transA = 0: A stored [M][K];  1: stored [K][M].  transB = 0: B stored [K][N];  1: stored [N][K]
+    int nz1;                          // inner batch extent: z = z0 * nz1 + z1
+    long long sA0, sA1, sB0, sB1, sC0, sC1;
+    float alpha;
+};
+
+__global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
+    constexpr int BM = 64, BN = 64, BK = 32, LDT = BM + 4;      // +4: the transposing stores spread over banks
+    __shared__ float As[BK * LDT], Bs[BK * LDT];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int z = blockIdx.z, z0 = z / g.nz1, z1 = z - z0 * g.nz1;
+    const float* A = g.A + z0 * g.sA0 + z1 * g.sA1;
+    const float* B = g.B + z0 * g.sB0 + z1 * g.sB1;
+    float* C = g.C + z0 * g.sC0 + z1 * g.sC1;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    wg_f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int li = lane & 31, lh = lane >> 5;
+    for (int k0 = 0; k0 < g.K; k0 += BK) {
+        __syncthreads();
+        // A tile -> As[k][m], B tile -> Bs[k][n]: 2048 elements each, 8 per thread; the index that is contiguous in memory runs fastest
+        for (int e = tid; e < BM * BK; e += 256) {
+            int m, k;
+            if (g.transA) { m = e % BM; k = e / BM; } else { k = e % BK; m = e / BK; }
+            const int gm = m0 + m, gk = k0 + k;
+            float v = 0.f;
+            if (gm < g.M && gk < g.K) v = g.transA ? A[(long long)gk * g.lda + gm] : A[(long long)gm * g.lda + gk];
+            As[k * LDT + m] = v;
+        }
+        for (int e = tid; e < BN * BK; e += 256) {
+            int n, k;
+            if (g.transB) { k = e % BK; n = e / BK; } else { n = e % BN; k = e / BN; }
+            const int gn = n0 + n, gk = k0 + k;
+            float v = 0.f;
+            if (gn < g.N && gk < g.K) v = g.transB ? B[(long long)gn * g.ldb + gk] : B[(long long)gk * g.ldb + gn];
+            Bs[k * LDT + n] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            const float av = As[(kk + lh) * LDT + wm * 32 + li];
+            const float bv = Bs[(kk + lh) * LDT + wn * 32 + li];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, n = n0 + wn * 32 + li;
+        if (m < g.M && n < g.N) C[(long long)m * g.ldc + n] = g.alpha * acc[r];
+    }
+}
+
+void launch_gemm_f32(const GemmArgs& g, int nz, hipStream_t stream) {
+    hipLaunchKernelGGL(gemm_f32_kernel, dim3((g.N + 63) / 64, (g.M + 63) / 64, nz), dim3(256), 0, stream, g);
+}
+
+// row softmax in place: one workgroup per row of an [rows][n] matrix
+__global__ __launch_bounds__(256) void softmax_rows_kernel(float* __restrict__ s, int n) {
+    __shared__ float red[256];
+    float* row = s + (size_t)blockIdx.x * n;
+    const int tid = threadIdx.x;
+    float mx = -3.0e38f;
+    for (int i = tid; i < n; i += 256) mx = fmaxf(mx, row[i]);
+    red[tid] = mx;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] = fmaxf(red[tid], red[tid + o]); __syncthreads(); }
+    mx = red[0];
+    __syncthreads();
+    float sum = 0.f;
+    for (int i = tid; i < n; i += 256) { const float e = __expf(row[i] - mx); row[i] = e; sum += e; }
+    red[tid] = sum;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
+    const float inv = 1.0f / red[0];
+    for (int i = tid; i < n; i += 256) row[i] *= inv;
+}
+
+// dS = P o (dP - rowsum(dP o P)) in place of dP: one workgroup per row
+__global__ __launch_bounds__(256) void softmax_bwd_rows_kernel(const float* __restrict__ p, float* __restrict__ dp, int n) {
+    __shared__ float red[256];
+    const float* pr = p + (size_t)blockIdx.x * n;
+    float* dr = dp + (size_t)blockIdx.x * n;
+    const int tid = threadIdx.x;
+    float d = 0.f;
+    for (int i = tid; i < n; i += 256) d += pr[i] * dr[i];
+    red[tid] = d;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
+    d = red[0];
+    for (int i = tid; i < n; i += 256) dr[i] = pr[i] * (dr[i] - d);
+}
+
+// QKVAttention backward (src/models/modules/OpenAI_Unet.py:457-476, new attention order): qkv NHWC [B][N][3C] = (q | k | v), heads =
+// contiguous groups of 64 channels; w = softmax((q s)^T (k s)), s = 64^-1/4; a = w v. Given da [B][N][C] writes dqkv [B][N][3C].
+// p, dp: scratch [B * heads][N][N] each (the probabilities are recomputed, not stored by the forward).
+void launch_attention_backward(const float* qkv, const float* da, float* dqkv, float* p, float* dp, int B, int N, int C,
+                               hipStream_t stream) {
+    const int heads = C / 64, nz = B * heads;
+    const long long row = 3LL * C, NN = (long long)N * N;
+    GemmArgs g;
+    g.nz1 = heads;
+    // S = Q K^T / 8
+    g.A = qkv; g.lda = row; g.transA = 0; g.sA0 = (long long)N * row; g.sA1 = 64;
+    g.B = qkv + C; g.ldb = row; g.transB = 1; g.sB0 = (long long)N * row; g.sB1 = 64;
+    g.C = p; g.ldc = N; g.sC0 = heads * NN; g.sC1 = NN;
+    g.M = N; g.N = N; g.K = 64; g.alpha = 0.125f;
+    launch_gemm_f32(g, nz, stream);
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)((long long)nz * N)), dim3(256), 0, stream, p, N);
+    // dV = P^T dA
+    g.A = p; g.lda = N; g.transA = 1; g.sA0 = heads * NN; g.sA1 = NN;
+    g.B = da; g.ldb = C; g.transB = 0; g.sB0 = (long long)N * C; g.sB1 = 64;
+    g.C = dqkv + 2 * C; g.ldc = row; g.sC0 = (long long)N * row; g.sC1 = 64;
+    g.M = N; g.N = 64; g.K = N; g.alpha = 1.0f;
+    launch_gemm_f32(g, nz, stream);
+    // dP = dA V^T
+    g.A = da; g.lda = C; g.transA = 0; g.sA0 = (long long)N * C; g.sA1 = 64;
+    g.B = qkv + 2 * C; g.ldb = row; g.transB = 1; g.sB0 = (long long)N * row; g.sB1 = 64;
+    g.C = dp; g.ldc = N; g.sC0 = heads * NN; g.sC1 = NN;
+    g.M = N; g.N = N; g.K = 64; g.alpha = 1.0f;
+    launch_gemm_f32(g, nz, stream);
+    hipLaunchKernelGGL(softmax_bwd_rows_kernel, dim3((unsigned)((long long)nz * N)), dim3(256), 0, stream, p, dp, N);
+    // dQ = dS K / 8
+    g.A = dp; g.lda = N; g.transA = 0; g.sA0 = heads * NN; g.sA1 = NN;
+    g.B = qkv + C; g.ldb = row; g.transB = 0; g.sB0 = (long long)N * row; g.sB1 = 64;
+    g.C = dqkv; g.ldc = row; g.sC0 = (long long)N * row; g.sC1 = 64;
+    g.M = N; g.N = 64; g.K = N; g.alpha = 0.125f;
+    launch_gemm_f32(g, nz, stream);
+    // dK = dS^T Q / 8
+    g.A = dp; g.lda = N; g.transA = 1;
+    g.B = qkv; g.ldb = row; g.transB = 0; g.sB0 = (long long)N * row; g.sB1 = 64;
+    g.C = dqkv + C;
+    launch_gemm_f32(g, nz, stream);
+}
+
+// y = act(x) W^T + b (torch.nn.Linear, optional SiLU on the input: emb_layers = Sequential(SiLU, Linear), OpenAI_Unet.py:201-207):
+// given dy [M][N]: dW [N][K] = dy^T act(x), db [N] = column sums of dy, dx [M][K] = (dy W) o act'(x).  a_scratch: [M][K] (act(x))
+__global__ void silu_rows_kernel(const float* __restrict__ x, float* __restrict__ a, long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) a[i] = silu_t(x[i]);
+}
+__global__ void silu_bwd_mul_kernel(const float* __restrict__ x, float* __restrict__ dx, long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dx[i] = dact(x[i], dx[i], 1);
+}
+__global__ void colsum_kernel(const float* __restrict__ dy, int M, int N, float* __restrict__ db) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    double s = 0;
+    for (int m = 0; m < M; ++m) s += dy[(size_t)m * N + n];
+    db[n] = (float)s;
+}
+
+void launch_linear_backward(const float* x, const float* W, const float* dy, int M, int N, int K, int silu_in, float* a_scratch,
+                            float* dW, float* db, float* dx, hipStream_t stream) {
+    const float* act = x;
+    if (silu_in) {
+        const long long n = (long long)M * K;
+        hipLaunchKernelGGL(silu_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, x, a_scratch, n);
+        act = a_scratch;
+    }
+    GemmArgs g;
+    g.nz1 = 1; g.sA0 = g.sA1 = g.sB0 = g.sB1 = g.sC0 = g.sC1 = 0; g.alpha = 1.0f;
+    // dW [N][K] = dy^T [N][M] . act [M][K]
+    g.A = dy; g.lda = N; g.transA = 1; g.B = act; g.ldb = K; g.transB = 0; g.C = dW; g.ldc = K; g.M = N; g.N = K; g.K = M;
+    launch_gemm_f32(g, 1, stream);
+    if (db) hipLaunchKernelGGL(colsum_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, dy, M, N, db);
+    if (dx) {
+        // dx [M][K] = dy [M][N] . W [N][K]
+        g.A = dy; g.lda = N; g.transA = 0; g.B = W; g.ldb = K; g.transB = 0; g.C = dx; g.ldc = K; g.M = M; g.N = K; g.K = N;
+        launch_gemm_f32(g, 1, stream);
+        if (silu_in) {
+            const long long n = (long long)M * K;
+            hipLaunchKernelGGL(silu_bwd_mul_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, x, dx, n);
+        }
+    }
+}
+
 }  // namespace cddpm

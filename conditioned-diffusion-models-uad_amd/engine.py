@@ -405,6 +405,24 @@ class CddpmEngine:
                                               dw.data_ptr(), db.data_ptr(), B, H, W, _stream_ptr(self.device)), "cddpm_op_conv_wgrad")
         return dw, db
 
+    def op_attention_backward(self, qkv, da):
+        """dL/dqkv [B,N,3C] of the attention core for da = dL/d(output) [B,N,C]"""
+        B, N, C3 = qkv.shape
+        dqkv = torch.empty_like(qkv)
+        self._ck(self.lib.cddpm_op_attention_backward(self._h, qkv.data_ptr(), da.data_ptr(), dqkv.data_ptr(), B, N, C3 // 3,
+                                                      _stream_ptr(self.device)), "cddpm_op_attention_backward")
+        return dqkv
+
+    def op_linear_backward(self, x, w, dy, silu_in=False):
+        """backward of y = [SiLU](x) W^T + b: x [M,K], w [N,K], dy [M,N] on the device -> (dW, db, dx)"""
+        M, K = x.shape
+        N = w.shape[0]
+        dw, db, dx = torch.empty_like(w), torch.empty((N,), dtype=torch.float32, device=self.device), torch.empty_like(x)
+        self._ck(self.lib.cddpm_op_linear_backward(self._h, x.data_ptr(), w.data_ptr(), dy.data_ptr(), M, N, K, int(bool(silu_in)),
+                                                   dw.data_ptr(), db.data_ptr(), dx.data_ptr(), _stream_ptr(self.device)),
+                 "cddpm_op_linear_backward")
+        return dw, db, dx
+
     def op_gn_silu_backward(self, x, da, gamma, beta, film, silu=True):
         """backward of act(GroupNorm32(x) * (1 + scale) + shift): x, da NHWC [B,H,W,C] -> (dx, dgamma, dbeta, dfilm or None)"""
         B, H, W, C = x.shape

@@ -255,6 +255,16 @@ int cddpm_op_conv_dgrad(cddpm_handle h, const float* dy_dev, int Cout, const flo
  * C0 + C1 a multiple of 32 (k = 3) or 64 (k = 1), C0 a multiple of 64 when C1 > 0, Cout of 64, H of 4. */
 int cddpm_op_conv_wgrad(cddpm_handle h, const float* x0_dev, int C0, const float* x1_dev, int C1, const float* coef_dev, int silu,
                         const float* dy_dev, int Cout, int ksize, float* dw_dev, float* db_dev, int B, int H, int W, void* stream);
+/* backward of the attention core QKVAttention (src/models/modules/OpenAI_Unet.py:457-476): qkv_dev [B,N,3C] (q | k | v, heads of 64
+ * channels), da_dev [B,N,C] = dL/d(output) -> dqkv_dev [B,N,3C]. The probabilities are recomputed (2 x B x C/64 x N x N floats of
+ * scratch are allocated for the call). */
+int cddpm_op_attention_backward(cddpm_handle h, const float* qkv_dev, const float* da_dev, float* dqkv_dev, int B, int N, int C,
+                                void* stream);
+/* backward of torch.nn.Linear behind an optional SiLU, y = [SiLU](x) W^T + b (emb_layers / time_embed / label_emb,
+ * OpenAI_Unet.py:201-207, :583-602): x_dev [M,K], w_dev [N,K], dy_dev [M,N] -> dw_dev [N,K], db_dev [N] (may be NULL), dx_dev [M,K]
+ * (may be NULL). */
+int cddpm_op_linear_backward(cddpm_handle h, const float* x_dev, const float* w_dev, const float* dy_dev, int M, int N, int K,
+                             int silu_in, float* dw_dev, float* db_dev, float* dx_dev, void* stream);
 /* backward of a = act(GroupNorm32(x) * (1 + scale) + shift), act = SiLU (silu != 0) or identity (OpenAI_Unet.py:284-338, :325-330):
  * given da_dev [B,HW,C] writes dx_dev [B,HW,C], dgamma_dev / dbeta_dev [C] and, when film_dev ([B][2C] scale | shift) is given,
  * dfilm_dev [B][2C]. The forward statistics are recomputed from x_dev. Everything NHWC fp32. */

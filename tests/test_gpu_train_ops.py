@@ -93,3 +93,39 @@ def test_conv_wgrad_vs_autograd(eng, C0, C1, Cout, k, H, W, act):
     eb = float((db.double().cpu() - bias.grad).abs().max() / bias.grad.abs().max())
     print(C0, C1, Cout, k, H, W, act, f"dW rel {ew:.2e}  db rel {eb:.2e}")
     assert ew < 1e-5 and eb < 1e-5
+
+
+@pytest.mark.parametrize("N", [16, 64, 576, 1024])
+def test_attention_backward_vs_autograd(eng, N):
+    """QKVAttention (OpenAI_Unet.py:457-476, new order): dL/dq, dL/dk, dL/dv; N = 576 is the 96x96 experiment's middle block
+    (not a multiple of the 64-wide GEMM tiles), 1024 the 128x128 one"""
+    torch.manual_seed(N)
+    B, C, ch = 2, 256, 64
+    heads = C // ch
+    qkv = torch.randn(B, 3 * C, N, dtype=torch.float64, requires_grad=True)
+    q, k, v = qkv.chunk(3, dim=1)
+    s = 1 / (ch ** 0.25)
+    w = torch.softmax(torch.einsum("bct,bcs->bts", (q * s).reshape(B * heads, ch, N), (k * s).reshape(B * heads, ch, N)), dim=-1)
+    a = torch.einsum("bts,bcs->bct", w, v.reshape(B * heads, ch, N)).reshape(B, C, N)
+    da = torch.randn(B, C, N, dtype=torch.float64)
+    a.backward(da)
+    got = eng.op_attention_backward(qkv.detach().permute(0, 2, 1).contiguous().float().cuda(),
+                                    da.permute(0, 2, 1).contiguous().float().cuda()).cpu().double().permute(0, 2, 1)
+    rel = float((got - qkv.grad).abs().max() / qkv.grad.abs().max())
+    print(N, f"dqkv rel {rel:.2e}")
+    assert rel < 1e-5
+
+
+@pytest.mark.parametrize("M,N,K,silu", [(2, 256, 1024, True), (16, 11776, 1024, True), (7, 512, 128, False), (1000, 512, 512, True)])
+def test_linear_backward_vs_autograd(eng, M, N, K, silu):
+    """emb_layers (SiLU -> Linear(1024, 2 Cout), all 27 ResBlocks as one [11776, 1024] matrix), time_embed / label_emb MLPs"""
+    torch.manual_seed(M + N + K)
+    x = torch.randn(M, K, dtype=torch.float64, requires_grad=True)
+    w = (torch.randn(N, K, dtype=torch.float64) / K ** 0.5).requires_grad_(True)
+    b = torch.zeros(N, dtype=torch.float64, requires_grad=True)
+    dy = torch.randn(M, N, dtype=torch.float64)
+    F.linear(F.silu(x) if silu else x, w, b).backward(dy)
+    dw, db, dx = eng.op_linear_backward(x.detach().float().cuda(), w.detach().float().cuda(), dy.float().cuda(), silu_in=silu)
+    r = [float((g.cpu().double() - t).abs().max() / t.abs().max()) for g, t in ((dw, w.grad), (db, b.grad), (dx, x.grad))]
+    print(M, N, K, silu, [f"{v:.2e}" for v in r])
+    assert max(r) < 1e-5
