@@ -78,9 +78,21 @@ SYMBOLS = {
     "cddpm_encoder_load_weights": (_i, [_vp, C.POINTER(C.c_char_p), C.POINTER(_fp), C.POINTER(_i64), _i]),
     "cddpm_encoder_forward": (_i, [_vp, _fp, _fp, _i, _i, _i, _vp]),
     "cddpm_op_conv_dgrad": (_i, [_vp, _fp, _i, _fp, _i, _i, _fp, _i, _i, _i, _vp]),
-    "cddpm_op_conv_wgrad": (_i, [_vp, _fp, _i, _fp, _i, _fp, _i, _fp, _i, _i, _fp, _fp, _i, _i, _i, _vp]),
+    "cddpm_op_conv_wgrad": (_i, [_vp, _fp, _i, _fp, _i, _fp, _i, _i, _fp, _i, _i, _fp, _fp, _i, _i, _i, _vp]),
+    "cddpm_op_bias_grad": (_i, [_vp, _fp, _i64, _i, _fp, _vp]),
     "cddpm_op_attention_backward": (_i, [_vp, _fp, _fp, _fp, _i, _i, _i, _vp]),
     "cddpm_op_linear_backward": (_i, [_vp, _fp, _fp, _fp, _i, _i, _i, _i, _fp, _fp, _fp, _vp]),
+    "cddpm_op_linear": (_i, [_vp, _fp, _fp, _fp, _i, _i, _i, _i, _fp, _vp]),
+    "cddpm_op_conv_in1": (_i, [_vp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _vp]),
+    "cddpm_op_head": (_i, [_vp, _fp, _fp, _fp, C.c_float, _fp, _i, _i, _i, _i, _vp]),
+    "cddpm_op_pool_act": (_i, [_vp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _vp]),
+    "cddpm_op_unpool2": (_i, [_vp, _fp, _fp, _i, _i, _i, _i, C.c_float, _i, _vp]),
+    "cddpm_op_sumpool2": (_i, [_vp, _fp, _fp, _i, _i, _i, _i, _i, _vp]),
+    "cddpm_op_add_inplace": (_i, [_vp, _fp, _fp, _i64, _vp]),
+    "cddpm_op_chan_image_corr": (_i, [_vp, _fp, _fp, _i, _fp, _i, _fp, _i, _i, _i, _i, _vp]),
+    "cddpm_op_head_dgrad": (_i, [_vp, _fp, _fp, _fp, _i, _i, _i, _i, _vp]),
+    "cddpm_op_loss": (_i, [_vp, _fp, _fp, _fp, _i, _i, _i, _fp, _fp, _vp]),
+    "cddpm_op_adam": (_i, [_vp, _fp, _fp, _fp, _fp, _i64, C.c_float, C.c_float, C.c_float, C.c_float, _i, _vp]),
     "cddpm_op_gn_silu_backward": (_i, [_vp, _fp, _fp, _fp, _fp, _fp, _i, _fp, _fp, _fp, _fp, _i, _i, _i, _vp]),
     "cddpm_stat_records": (_i, [_i, _i, _i]),
     "cddpm_packed_conv_bytes": (_sz, [_i, _i, _i]),

@@ -1475,12 +1475,22 @@ int cddpm_op_conv_dgrad(cddpm_handle h, const float* dy_dev, int Cout, const flo
     return 0;
 }
 
+int cddpm_op_bias_grad(cddpm_handle h, const float* dy_dev, int64_t npix, int C, float* db_dev, void* stream) {
+    if (!h) return -1;
+    if (!dy_dev || !db_dev || npix < 1 || C % 4) return fail(h, "cddpm_op_bias_grad: bad arguments");
+    HIPCHECK(h, hipSetDevice(h->device));
+    launch_bias_grad(dy_dev, npix, C, db_dev, (hipStream_t)stream);
+    HIPCHECK(h, hipGetLastError());
+    return 0;
+}
+
 int cddpm_op_conv_wgrad(cddpm_handle h, const float* x0_dev, int C0, const float* x1_dev, int C1, const float* coef_dev, int silu,
-                        const float* dy_dev, int Cout, int ksize, float* dw_dev, float* db_dev, int B, int H, int W, void* stream) {
+                        int upsample, const float* dy_dev, int Cout, int ksize, float* dw_dev, float* db_dev, int B, int H, int W,
+                        void* stream) {
     if (!h) return -1;
     const int Cin = C0 + C1, taps = ksize * ksize, ck = (ksize == 3) ? 32 : 64;
     if ((ksize != 1 && ksize != 3) || C0 <= 0 || C1 < 0 || Cin % ck || (C1 > 0 && C0 % 64) || Cout <= 0 || Cout % 64 || H < 4 || H % 4 ||
-        W < 1 || B < 1 || (C1 > 0 && !x1_dev))
+        W < 1 || B < 1 || (C1 > 0 && !x1_dev) || (upsample && (C1 > 0 || (W & 1))))
         return fail(h, "cddpm_op_conv_wgrad: unsupported shape (k %d, C0 %d, C1 %d, Cout %d, H %d)", ksize, C0, C1, Cout, H);
     if (!x0_dev || !dy_dev || !dw_dev) return fail(h, "cddpm_op_conv_wgrad: NULL argument");
     hipStream_t s = (hipStream_t)stream;
@@ -1488,7 +1498,7 @@ int cddpm_op_conv_wgrad(cddpm_handle h, const float* x0_dev, int C0, const float
     const int P = conv_wgrad_parts(B, H, W, Cin, Cout, taps);
     float* part = nullptr;
     HIPCHECK(h, hipMalloc((void**)&part, (size_t)P * Cout * Cin * taps * sizeof(float)));
-    launch_conv_wgrad(x0_dev, C0, x1_dev, C1, coef_dev, silu, dy_dev, B, H, W, Cout, taps, part, P, dw_dev, db_dev, s);
+    launch_conv_wgrad(x0_dev, C0, x1_dev, C1, coef_dev, silu, upsample ? 1 : 0, dy_dev, B, H, W, Cout, taps, part, P, dw_dev, db_dev, s);
     HIPCHECK(h, hipGetLastError());
     HIPCHECK(h, hipStreamSynchronize(s));
     (void)hipFree(part);
@@ -1526,6 +1536,87 @@ int cddpm_op_linear_backward(cddpm_handle h, const float* x_dev, const float* w_
     HIPCHECK(h, hipStreamSynchronize(s));
     if (a) (void)hipFree(a);
     return 0;
+}
+
+#define OP_PROLOGUE(cond, msg)                                   \
+    if (!h) return -1;                                            \
+    if (!(cond)) return fail(h, msg);                             \
+    hipStream_t s = (hipStream_t)stream;                          \
+    HIPCHECK(h, hipSetDevice(h->device));
+#define OP_EPILOGUE()                                             \
+    HIPCHECK(h, hipGetLastError());                               \
+    return 0;
+
+int cddpm_op_linear(cddpm_handle h, const float* x_dev, const float* w_dev, const float* b_dev, int M, int N, int K, int silu_in,
+                    float* y_dev, void* stream) {
+    OP_PROLOGUE(x_dev && w_dev && y_dev && M > 0 && N > 0 && K > 0, "cddpm_op_linear: bad arguments")
+    launch_linear(x_dev, K, w_dev, K, 0, b_dev, y_dev, N, M, N, K, silu_in, s);
+    OP_EPILOGUE()
+}
+int cddpm_op_conv_in1(cddpm_handle h, const float* x_dev, const float* w_dev, const float* b_dev, float* out_dev, int B, int H, int W,
+                      int C, void* stream) {
+    OP_PROLOGUE(x_dev && w_dev && b_dev && out_dev && C % 64 == 0 && C <= 512, "cddpm_op_conv_in1: bad arguments")
+    launch_conv_in1(x_dev, w_dev, b_dev, out_dev, B, H, W, C, s);
+    OP_EPILOGUE()
+}
+int cddpm_op_head(cddpm_handle h, const float* x_dev, const float* coef_dev, const float* w9_dev, float bias, float* out_dev, int B,
+                  int H, int W, int C, void* stream) {
+    OP_PROLOGUE(x_dev && coef_dev && w9_dev && out_dev && C % 32 == 0, "cddpm_op_head: bad arguments")
+    float* P = nullptr;
+    HIPCHECK(h, hipMalloc((void**)&P, (size_t)B * H * W * 9 * sizeof(float)));
+    launch_head_dots(x_dev, coef_dev, w9_dev, P, B, H * W, C, s);
+    launch_head_gather(P, bias, out_dev, B, H, W, s);
+    HIPCHECK(h, hipStreamSynchronize(s));
+    (void)hipFree(P);
+    OP_EPILOGUE()
+}
+int cddpm_op_pool_act(cddpm_handle h, const float* x_dev, const float* coef_dev, float* hp_dev, float* xp_dev, int B, int H, int W, int C,
+                      void* stream) {
+    OP_PROLOGUE(x_dev && coef_dev && hp_dev && xp_dev && H % 2 == 0 && W % 2 == 0 && C % 4 == 0, "cddpm_op_pool_act: bad arguments")
+    launch_pool_act(x_dev, coef_dev, hp_dev, xp_dev, B, H, W, C, s);
+    OP_EPILOGUE()
+}
+int cddpm_op_unpool2(cddpm_handle h, const float* dyp_dev, float* dx_dev, int B, int H, int W, int C, float scale, int accumulate, void* stream) {
+    OP_PROLOGUE(dyp_dev && dx_dev && H % 2 == 0 && W % 2 == 0 && C % 4 == 0, "cddpm_op_unpool2: bad arguments")
+    launch_unpool2(dyp_dev, dx_dev, B, H, W, C, scale, accumulate, s);
+    OP_EPILOGUE()
+}
+int cddpm_op_sumpool2(cddpm_handle h, const float* dy_dev, float* dxp_dev, int B, int H, int W, int C, int accumulate, void* stream) {
+    OP_PROLOGUE(dy_dev && dxp_dev && H % 2 == 0 && W % 2 == 0 && C % 4 == 0, "cddpm_op_sumpool2: bad arguments")
+    launch_sumpool2(dy_dev, dxp_dev, B, H, W, C, accumulate, s);
+    OP_EPILOGUE()
+}
+int cddpm_op_add_inplace(cddpm_handle h, float* a_dev, const float* b_dev, int64_t n, void* stream) {
+    OP_PROLOGUE(a_dev && b_dev && n > 0 && n % 4 == 0, "cddpm_op_add_inplace: bad arguments")
+    launch_add_inplace(a_dev, b_dev, n, s);
+    OP_EPILOGUE()
+}
+int cddpm_op_chan_image_corr(cddpm_handle h, const float* t_dev, const float* coef_dev, int silu, const float* s_dev, int sign, float* dw_dev,
+                             int B, int H, int W, int C, void* stream) {
+    OP_PROLOGUE(t_dev && s_dev && dw_dev && C % 64 == 0 && (sign == 1 || sign == -1), "cddpm_op_chan_image_corr: bad arguments")
+    double* part = nullptr;
+    HIPCHECK(h, hipMalloc((void**)&part, (size_t)64 * C * 9 * sizeof(double)));
+    launch_chan_image_corr(t_dev, coef_dev, silu, s_dev, sign, B, H, W, C, part, dw_dev, s);
+    HIPCHECK(h, hipStreamSynchronize(s));
+    (void)hipFree(part);
+    OP_EPILOGUE()
+}
+int cddpm_op_head_dgrad(cddpm_handle h, const float* dout_dev, const float* w9_dev, float* dact_dev, int B, int H, int W, int C, void* stream) {
+    OP_PROLOGUE(dout_dev && w9_dev && dact_dev && C % 4 == 0, "cddpm_op_head_dgrad: bad arguments")
+    launch_head_dgrad(dout_dev, w9_dev, dact_dev, B, H, W, C, s);
+    OP_EPILOGUE()
+}
+int cddpm_op_loss(cddpm_handle h, const float* out_dev, const float* target_dev, const float* w_b_dev, int l2, int B, int HW, float* dout_dev,
+                  float* loss_b_dev, void* stream) {
+    OP_PROLOGUE(out_dev && target_dev && dout_dev && loss_b_dev && B > 0 && HW > 0, "cddpm_op_loss: bad arguments")
+    launch_loss(out_dev, target_dev, w_b_dev, l2, B, HW, dout_dev, loss_b_dev, s);
+    OP_EPILOGUE()
+}
+int cddpm_op_adam(cddpm_handle h, float* p_dev, const float* g_dev, float* m_dev, float* v_dev, int64_t n, float lr, float beta1, float beta2,
+                  float eps, int step, void* stream) {
+    OP_PROLOGUE(p_dev && g_dev && m_dev && v_dev && n > 0 && step >= 1, "cddpm_op_adam: bad arguments")
+    launch_adam(p_dev, g_dev, m_dev, v_dev, n, lr, beta1, beta2, eps, step, s);
+    OP_EPILOGUE()
 }
 
 int cddpm_op_gn_silu_backward(cddpm_handle h, const float* x_dev, const float* da_dev, const float* gamma_host,

@@ -153,8 +153,9 @@ void launch_gn_bwd_planes(const float* rec, int nrec, const float* gamma, const 
 // conv wgrad (3x3 pad 1, or 1x1): dw [Cout][Cin][k][k] (PyTorch layout), db [Cout] or nullptr; input = cat[x0 (C0), x1 (C1)];
 // part: scratch of conv_wgrad_parts() * Cout * Cin * taps floats. Cin multiple of 32 (3x3) / 64 (1x1), C0 of 64, Cout of 64, H of 4
 int conv_wgrad_parts(int B, int H, int W, int Cin, int Cout, int taps);
-void launch_conv_wgrad(const float* x0, int C0, const float* x1, int C1, const float* coef, int silu, const float* dy, int B, int H,
+void launch_conv_wgrad(const float* x0, int C0, const float* x1, int C1, const float* coef, int silu, int up, const float* dy, int B, int H,
                        int W, int Cout, int taps, float* part, int P, float* dw, float* db, hipStream_t stream);
+void launch_bias_grad(const float* dy, long long npix, int C, float* db, hipStream_t stream);
 // QKVAttention backward: qkv [B][N][3C] (q | k | v), da [B][N][C] -> dqkv [B][N][3C]; p, dp: scratch [B * C / 64][N][N] floats each
 void launch_attention_backward(const float* qkv, const float* da, float* dqkv, float* p, float* dp, int B, int N, int C,
                                hipStream_t stream);
@@ -162,6 +163,17 @@ void launch_attention_backward(const float* qkv, const float* da, float* dqkv, f
 // a_scratch [M][K] when silu_in
 void launch_linear_backward(const float* x, const float* W, const float* dy, int M, int N, int K, int silu_in, float* a_scratch,
                             float* dW, float* db, float* dx, hipStream_t stream);
+void launch_unpool2(const float* dyp, float* dx, int B, int H, int W, int C, float scale, int accumulate, hipStream_t stream);
+void launch_sumpool2(const float* dy, float* dxp, int B, int H, int W, int C, int accumulate, hipStream_t stream);
+void launch_add_inplace(float* a, const float* b, long long n, hipStream_t stream);
+// dw [C][9] = sum_{b,q} act(T)[b,q,c] * simg[b, q + sign * tap]; part: 64 * C * 9 doubles of scratch
+void launch_chan_image_corr(const float* T, const float* coef, int silu, const float* simg, int sign, int B, int H, int W, int C,
+                            double* part, float* dw, hipStream_t stream);
+void launch_head_dgrad(const float* dout, const float* w9, float* dact, int B, int H, int W, int C, hipStream_t stream);
+void launch_loss(const float* out, const float* target, const float* w_b, int l2, int B, int HW, float* dout, float* loss_b,
+                 hipStream_t stream);
+void launch_adam(float* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2, float eps, int step,
+                 hipStream_t stream);
 void launch_gn_silu_backward(const float* x, const float* da, const float* planes, const float* gamma, const float* beta,
                              const float* film, int silu, int B, int C, int HW, int nsplit, double* part, float* out_bc, float* dx,
                              float* dgamma, float* dbeta, float* dfilm, hipStream_t stream);

@@ -235,6 +235,7 @@ struct WgradArgs {
     int C0, C1;
     const float* coef;     // [3][B][Cin] (mean, a, d) over the concatenated channels: act input = (x - mean) * a + d, or nullptr
     int silu;
+    int up;                // 1: the conv input is the nearest x2 upsampling of act(x): x is [B,H/2,W/2,C], read at (y >> 1, x >> 1)
     const float* dy;       // NHWC [B,H,W,Cout]
     int B, H, W, Cout;
     float* part;           // [P][Cout/64][Cin/CK][64 co][TAPS][CK ci]
@@ -296,7 +297,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a) {
             const int y = y0 + pr - PAD, x = x0 + pc - PAD;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (y >= 0 && y < a.H && x >= 0 && x < a.W) {
-                v = *reinterpret_cast<const float4*>(xsrc + ((size_t)(b * a.H + y) * a.W + x) * Cs + cs0 + 4 * c4);
+                const size_t sp = a.up ? ((size_t)(b * (a.H >> 1) + (y >> 1)) * (a.W >> 1) + (x >> 1)) : ((size_t)(b * a.H + y) * a.W + x);
+                v = *reinterpret_cast<const float4*>(xsrc + sp * Cs + cs0 + 4 * c4);
                 if (a.coef) {
                     const size_t pl = (size_t)a.B * Cin, bc = (size_t)b * Cin + ch0 + 4 * c4;
                     const float4 m = *reinterpret_cast<const float4*>(a.coef + bc), g = *reinterpret_cast<const float4*>(a.coef + pl + bc);
@@ -387,10 +389,10 @@ int conv_wgrad_parts(int B, int H, int W, int Cin, int Cout, int taps) {
     return P < 1 ? 1 : P;
 }
 
-void launch_conv_wgrad(const float* x0, int C0, const float* x1, int C1, const float* coef, int silu, const float* dy, int B, int H,
+void launch_conv_wgrad(const float* x0, int C0, const float* x1, int C1, const float* coef, int silu, int up, const float* dy, int B, int H,
                        int W, int Cout, int taps, float* part, int P, float* dw, float* db, hipStream_t stream) {
     WgradArgs a;
-    a.x0 = x0; a.x1 = x1; a.C0 = C0; a.C1 = C1; a.coef = coef; a.silu = silu; a.dy = dy; a.B = B; a.H = H; a.W = W; a.Cout = Cout;
+    a.x0 = x0; a.x1 = x1; a.C0 = C0; a.C1 = C1; a.coef = coef; a.silu = silu; a.up = up; a.dy = dy; a.B = B; a.H = H; a.W = W; a.Cout = Cout;
     a.part = part; a.P = P;
     const int Cin = C0 + C1;
     const unsigned grid = (unsigned)(P * (Cout / 64) * (Cin / (taps == 9 ? 32 : 64)));
@@ -589,6 +591,204 @@ void launch_linear_backward(const float* x, const float* W, const float* dy, int
             hipLaunchKernelGGL(silu_bwd_mul_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, x, dx, n);
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Elementwise / resampling backward pieces, NHWC fp32, 16 B per lane
+// ------------------------------------------------------------------------------------------------------------------
+// dx [B,H,W,C] (+)= dyp [B,H/2,W/2,C] at (y >> 1, x >> 1) * scale    (AvgPool2d(2) backward: scale = 1/4)
+__global__ __launch_bounds__(256) void unpool2_kernel(const float* __restrict__ dyp, float* __restrict__ dx, int B, int H, int W, int C,
+                                                      float scale, int accumulate) {
+    const int ncq = C >> 2;
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (long long)B * H * W * ncq) return;
+    const int cq = (int)(e % ncq);
+    const long long pix = e / ncq;
+    const int x = (int)(pix % W), y = (int)((pix / W) % H), b = (int)(pix / ((long long)W * H));
+    const float4 v = *reinterpret_cast<const float4*>(dyp + (((size_t)b * (H >> 1) + (y >> 1)) * (W >> 1) + (x >> 1)) * C + 4 * cq);
+    float4* o = reinterpret_cast<float4*>(dx + (size_t)pix * C + 4 * cq);
+    float4 r = make_float4(v.x * scale, v.y * scale, v.z * scale, v.w * scale);
+    if (accumulate) { const float4 t = *o; r.x += t.x; r.y += t.y; r.z += t.z; r.w += t.w; }
+    *o = r;
+}
+// dxp [B,H/2,W/2,C] (+)= sum of the 2x2 block of dy [B,H,W,C]    (nearest x2 upsample backward)
+__global__ __launch_bounds__(256) void sumpool2_kernel(const float* __restrict__ dy, float* __restrict__ dxp, int B, int H, int W, int C,
+                                                       int accumulate) {
+    const int ncq = C >> 2, h2 = H >> 1, w2 = W >> 1;
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (long long)B * h2 * w2 * ncq) return;
+    const int cq = (int)(e % ncq);
+    const long long pix = e / ncq;
+    const int x = (int)(pix % w2), y = (int)((pix / w2) % h2), b = (int)(pix / ((long long)w2 * h2));
+    float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int dy_ = 0; dy_ < 2; ++dy_)
+#pragma unroll
+        for (int dx_ = 0; dx_ < 2; ++dx_) {
+            const float4 v = *reinterpret_cast<const float4*>(dy + (((size_t)b * H + 2 * y + dy_) * W + 2 * x + dx_) * C + 4 * cq);
+            r.x += v.x; r.y += v.y; r.z += v.z; r.w += v.w;
+        }
+    float4* o = reinterpret_cast<float4*>(dxp + (size_t)pix * C + 4 * cq);
+    if (accumulate) { const float4 t = *o; r.x += t.x; r.y += t.y; r.z += t.z; r.w += t.w; }
+    *o = r;
+}
+__global__ __launch_bounds__(256) void add_inplace_kernel(float* __restrict__ a, const float* __restrict__ b, long long n4) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    float4 x = reinterpret_cast<float4*>(a)[i];
+    const float4 y = reinterpret_cast<const float4*>(b)[i];
+    x.x += y.x; x.y += y.y; x.z += y.z; x.w += y.w;
+    reinterpret_cast<float4*>(a)[i] = x;
+}
+void launch_unpool2(const float* dyp, float* dx, int B, int H, int W, int C, float scale, int accumulate, hipStream_t stream) {
+    const long long n = (long long)B * H * W * (C / 4);
+    hipLaunchKernelGGL(unpool2_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, dyp, dx, B, H, W, C, scale, accumulate);
+}
+void launch_sumpool2(const float* dy, float* dxp, int B, int H, int W, int C, int accumulate, hipStream_t stream) {
+    const long long n = (long long)B * (H / 2) * (W / 2) * (C / 4);
+    hipLaunchKernelGGL(sumpool2_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, dy, dxp, B, H, W, C, accumulate);
+}
+void launch_add_inplace(float* a, const float* b, long long n, hipStream_t stream) {
+    hipLaunchKernelGGL(add_inplace_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, stream, a, b, n / 4);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// The two single-channel convolutions at the ends of the UNet (input_blocks.0: Conv2d(1 -> C); out.2: Conv2d(C -> 1), OpenAI_Unet.py
+// :606-612, :793-797). Both weight gradients are a correlation of a C-channel tensor T with a one-channel image s:
+//     dW[c][tap] = sum_{b,q} T'[b,q,c] * s[b, q + sign * tap],   T' = act(T) (coefficient planes + SiLU) or T itself
+//   input conv : T = dL/d(output) [B,HW,C], s = the image x, sign = +1;   head conv: T = its input tensor, s = dL/d(out), sign = -1
+// and the head's input gradient is  d act[b,q,c] = sum_tap w[c][tap] * dout[b, q - tap].
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void chan_image_corr_kernel(const float* __restrict__ T, const float* __restrict__ coef, int silu,
+                                                              const float* __restrict__ simg, int sign, int B, int H, int W, int C,
+                                                              int nsplit, double* __restrict__ part /*[nsplit][C][9]*/) {
+    // workgroup = (pixel split, 64-channel block): thread = (channel quad of 16, pixel lane of 16)
+    __shared__ double red[16][16][37];
+    const int tid = threadIdx.x, cq = tid & 15, pl = tid >> 4;
+    const int split = blockIdx.x, cblk = blockIdx.y;
+    const int c0 = cblk * 64 + 4 * cq;
+    const long long npix = (long long)B * H * W;
+    const long long per = (npix + nsplit - 1) / nsplit, p0 = split * per, p1 = min(npix, p0 + per);
+    double acc[4][9];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc[i][t] = 0;
+    const size_t plane = (size_t)B * C;
+    for (long long p = p0 + pl; p < p1; p += 16) {
+        const int x = (int)(p % W), y = (int)((p / W) % H), b = (int)(p / ((long long)W * H));
+        float4 v = *reinterpret_cast<const float4*>(T + (size_t)p * C + c0);
+        if (coef) {
+            const size_t bc = (size_t)b * C + c0;
+            const float4 m = *reinterpret_cast<const float4*>(coef + bc), g = *reinterpret_cast<const float4*>(coef + plane + bc);
+            const float4 d = *reinterpret_cast<const float4*>(coef + 2 * plane + bc);
+            v.x = (v.x - m.x) * g.x + d.x; v.y = (v.y - m.y) * g.y + d.y; v.z = (v.z - m.z) * g.z + d.z; v.w = (v.w - m.w) * g.w + d.w;
+        }
+        if (silu) { v.x = silu_t(v.x); v.y = silu_t(v.y); v.z = silu_t(v.z); v.w = silu_t(v.w); }
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int yy = y + sign * (t / 3 - 1), xx = x + sign * (t % 3 - 1);
+            if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
+            const double sv = simg[((size_t)b * H + yy) * W + xx];
+            acc[0][t] += sv * v.x; acc[1][t] += sv * v.y; acc[2][t] += sv * v.z; acc[3][t] += sv * v.w;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) red[pl][cq][i * 9 + t] = acc[i][t];
+    __syncthreads();
+    for (int e = tid; e < 16 * 36; e += 256) {
+        const int q = e / 36, it = e % 36;
+        double sum = 0;
+        for (int l = 0; l < 16; ++l) sum += red[l][q][it];
+        part[((size_t)split * C + cblk * 64 + 4 * q + it / 9) * 9 + it % 9] = sum;
+    }
+}
+__global__ void corr_reduce_kernel(const double* __restrict__ part, int nsplit, int n, float* __restrict__ dw) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double s = 0;
+    for (int p = 0; p < nsplit; ++p) s += part[(size_t)p * n + i];
+    dw[i] = (float)s;
+}
+// part: scratch of 64 * C * 9 doubles;  dw [C][9]
+void launch_chan_image_corr(const float* T, const float* coef, int silu, const float* simg, int sign, int B, int H, int W, int C,
+                            double* part, float* dw, hipStream_t stream) {
+    const int nsplit = 64;
+    hipLaunchKernelGGL(chan_image_corr_kernel, dim3(nsplit, C / 64), dim3(256), 0, stream, T, coef, silu, simg, sign, B, H, W, C, nsplit, part);
+    hipLaunchKernelGGL(corr_reduce_kernel, dim3((C * 9 + 255) / 256), dim3(256), 0, stream, part, nsplit, C * 9, dw);
+}
+
+// head dgrad: dact[b,q,c] = sum_tap w9[tap][c] * dout[b, q - tap]    (w9: the head's [9][C] weight image)
+__global__ __launch_bounds__(256) void head_dgrad_kernel(const float* __restrict__ dout, const float* __restrict__ w9, float* __restrict__ dact,
+                                                         int B, int H, int W, int C) {
+    const int ncq = C >> 2;
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (long long)B * H * W * ncq) return;
+    const int cq = (int)(e % ncq);
+    const long long pix = e / ncq;
+    const int x = (int)(pix % W), y = (int)((pix / W) % H), b = (int)(pix / ((long long)W * H));
+    float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int yy = y - (t / 3 - 1), xx = x - (t % 3 - 1);
+        if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
+        const float d = dout[((size_t)b * H + yy) * W + xx];
+        const float4 w = *reinterpret_cast<const float4*>(w9 + (size_t)t * C + 4 * cq);
+        r.x += w.x * d; r.y += w.y * d; r.z += w.z * d; r.w += w.w * d;
+    }
+    *reinterpret_cast<float4*>(dact + (size_t)pix * C + 4 * cq) = r;
+}
+void launch_head_dgrad(const float* dout, const float* w9, float* dact, int B, int H, int W, int C, hipStream_t stream) {
+    const long long n = (long long)B * H * W * (C / 4);
+    hipLaunchKernelGGL(head_dgrad_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, dout, w9, dact, B, H, W, C);
+}
+
+// loss of p_losses (cond_DDPM.py:636-645): per-sample mean of |out - target| (l1) or (out - target)^2 (l2), times p2_loss_weight[t_b],
+// mean over the batch; writes dL/d(out) and the B per-sample terms (their mean is the loss)
+__global__ __launch_bounds__(256) void loss_kernel(const float* __restrict__ out, const float* __restrict__ target, const float* __restrict__ w_b,
+                                                   int l2, int B, int HW, float* __restrict__ dout, float* __restrict__ loss_b) {
+    __shared__ double red[256];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float wb = w_b ? w_b[b] : 1.0f;
+    const float gscale = wb / ((float)B * (float)HW);
+    double s = 0;
+    for (int p = tid; p < HW; p += 256) {
+        const float d = out[(size_t)b * HW + p] - target[(size_t)b * HW + p];
+        s += l2 ? (double)d * d : fabs((double)d);
+        dout[(size_t)b * HW + p] = l2 ? 2.0f * d * gscale : ((d > 0.f) - (d < 0.f)) * gscale;
+    }
+    red[tid] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
+    if (tid == 0) loss_b[b] = (float)(red[0] / HW * wb);
+}
+void launch_bias_grad(const float* dy, long long npix, int C, float* db, hipStream_t stream) {
+    hipLaunchKernelGGL(bias_grad_kernel, dim3(C / 4), dim3(256), 0, stream, dy, npix, C, db);
+}
+void launch_loss(const float* out, const float* target, const float* w_b, int l2, int B, int HW, float* dout, float* loss_b,
+                 hipStream_t stream) {
+    hipLaunchKernelGGL(loss_kernel, dim3(B), dim3(256), 0, stream, out, target, w_b, l2, B, HW, dout, loss_b);
+}
+
+// Adam (torch.optim.Adam defaults of DDPM_2D.configure_optimizers, DDPM_2D.py:305-306: lr 1e-4, betas (0.9, 0.999), eps 1e-8, no weight
+// decay) on a flat parameter vector: m, v fp32 state; bias corrections passed in
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                                   long long n, float lr, float b1, float b2, float eps, float bc1, float bc2) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float gi = g[i];
+    const float mi = b1 * m[i] + (1.0f - b1) * gi;
+    const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    const float denom = sqrtf(vi) / sqrtf(bc2) + eps;
+    p[i] -= (lr / bc1) * (mi / denom);
+}
+void launch_adam(float* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2, float eps, int step,
+                 hipStream_t stream) {
+    const float bc1 = 1.0f - powf(b1, (float)step), bc2 = 1.0f - powf(b2, (float)step);
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, p, g, m, v, n, lr, b1, b2, eps, bc1, bc2);
 }
 
 }  // namespace cddpm

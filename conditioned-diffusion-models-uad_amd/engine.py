@@ -393,7 +393,7 @@ class CddpmEngine:
                                               _stream_ptr(self.device)), "cddpm_op_conv_dgrad")
         return dx
 
-    def op_conv_wgrad(self, x0, x1, coef, silu, dy, ksize=3):
+    def op_conv_wgrad(self, x0, x1, coef, silu, dy, ksize=3, upsample=False):
         """dL/dW [Cout,Cin,k,k] and dL/db [Cout] of y = conv_k(act(cat[x0, x1])) for dy NHWC [B,H,W,Cout]; x0 / x1 NHWC, coef [3,B,Cin] or None"""
         B, H, W, C0 = x0.shape
         C1 = x1.shape[-1] if x1 is not None else 0
@@ -401,8 +401,9 @@ class CddpmEngine:
         dw = torch.empty((Cout, C0 + C1, ksize, ksize), dtype=torch.float32, device=self.device)
         db = torch.empty((Cout,), dtype=torch.float32, device=self.device)
         self._ck(self.lib.cddpm_op_conv_wgrad(self._h, x0.data_ptr(), C0, x1.data_ptr() if x1 is not None else None, C1,
-                                              coef.data_ptr() if coef is not None else None, int(bool(silu)), dy.data_ptr(), Cout, ksize,
-                                              dw.data_ptr(), db.data_ptr(), B, H, W, _stream_ptr(self.device)), "cddpm_op_conv_wgrad")
+                                              coef.data_ptr() if coef is not None else None, int(bool(silu)), int(bool(upsample)),
+                                              dy.data_ptr(), Cout, ksize, dw.data_ptr(), db.data_ptr(), dy.shape[0], dy.shape[1], dy.shape[2],
+                                              _stream_ptr(self.device)), "cddpm_op_conv_wgrad")
         return dw, db
 
     def op_attention_backward(self, qkv, da):

@@ -252,9 +252,13 @@ int cddpm_op_conv_dgrad(cddpm_handle h, const float* dy_dev, int Cout, const flo
 /* dL/d(weight), dL/d(bias) of y = Conv2d(k in {1,3}, padding k/2) applied to a = act(cat[x0, x1]) with act(v) = silu?((v - mean) *
  * a + d) as in cddpm_op_conv (coef_dev [3][B][C0 + C1] or NULL): dw_dev [Cout,Cin,k,k] (PyTorch layout) = sum over batch and pixels of
  * dy (x) a, db_dev [Cout] = sum of dy (may be NULL). x0_dev [B,H,W,C0], x1_dev [B,H,W,C1] or NULL (C1 = 0), dy_dev [B,H,W,Cout];
- * C0 + C1 a multiple of 32 (k = 3) or 64 (k = 1), C0 a multiple of 64 when C1 > 0, Cout of 64, H of 4. */
+ * C0 + C1 a multiple of 32 (k = 3) or 64 (k = 1), C0 a multiple of 64 when C1 > 0, Cout of 64, H of 4. upsample != 0: the conv
+ * input is the nearest x2 upsampling of act(x0) (up ResBlocks, OpenAI_Unet.py:289-293): x0_dev is [B,H/2,W/2,C0], H and W even. */
 int cddpm_op_conv_wgrad(cddpm_handle h, const float* x0_dev, int C0, const float* x1_dev, int C1, const float* coef_dev, int silu,
-                        const float* dy_dev, int Cout, int ksize, float* dw_dev, float* db_dev, int B, int H, int W, void* stream);
+                        int upsample, const float* dy_dev, int Cout, int ksize, float* dw_dev, float* db_dev, int B, int H, int W,
+                        void* stream);
+/* db_dev[C] = sum over the npix rows of dy_dev [npix][C] (bias gradient of a convolution) */
+int cddpm_op_bias_grad(cddpm_handle h, const float* dy_dev, int64_t npix, int C, float* db_dev, void* stream);
 /* backward of the attention core QKVAttention (src/models/modules/OpenAI_Unet.py:457-476): qkv_dev [B,N,3C] (q | k | v, heads of 64
  * channels), da_dev [B,N,C] = dL/d(output) -> dqkv_dev [B,N,3C]. The probabilities are recomputed (2 x B x C/64 x N x N floats of
  * scratch are allocated for the call). */
@@ -265,6 +269,34 @@ int cddpm_op_attention_backward(cddpm_handle h, const float* qkv_dev, const floa
  * (may be NULL). */
 int cddpm_op_linear_backward(cddpm_handle h, const float* x_dev, const float* w_dev, const float* dy_dev, int M, int N, int K,
                              int silu_in, float* dw_dev, float* db_dev, float* dx_dev, void* stream);
+/* small forward operators of the UNet as stand-alone entry points (the training step's host code sequences them; every pointer is a
+ * device pointer, NHWC fp32): y[M,N] = [SiLU](x[M,K]) w[N,K]^T + b (torch.nn.Linear); input_blocks.0 Conv2d(1 -> C, 3x3) with w [C][9];
+ * the head out.2 Conv2d(C -> 1, 3x3) on act(x) with w9 [9][C]; the down-ResBlock front end (hp = avgpool2(act(x)), xp = avgpool2(x)). */
+int cddpm_op_linear(cddpm_handle h, const float* x_dev, const float* w_dev, const float* b_dev, int M, int N, int K, int silu_in,
+                    float* y_dev, void* stream);
+int cddpm_op_conv_in1(cddpm_handle h, const float* x_dev, const float* w_dev, const float* b_dev, float* out_dev, int B, int H, int W,
+                      int C, void* stream);
+int cddpm_op_head(cddpm_handle h, const float* x_dev, const float* coef_dev, const float* w9_dev, float bias, float* out_dev, int B,
+                  int H, int W, int C, void* stream);
+int cddpm_op_pool_act(cddpm_handle h, const float* x_dev, const float* coef_dev, float* hp_dev, float* xp_dev, int B, int H, int W, int C,
+                      void* stream);
+/* resampling backward and accumulation: dx[B,H,W,C] (+)= scale * dyp[B,H/2,W/2,C] at (y/2, x/2) (AvgPool2d(2) backward: scale 1/4);
+ * dxp[B,H/2,W/2,C] (+)= 2x2 block sums of dy (nearest x2 upsample backward); a += b (n floats, multiple of 4). */
+int cddpm_op_unpool2(cddpm_handle h, const float* dyp_dev, float* dx_dev, int B, int H, int W, int C, float scale, int accumulate, void* stream);
+int cddpm_op_sumpool2(cddpm_handle h, const float* dy_dev, float* dxp_dev, int B, int H, int W, int C, int accumulate, void* stream);
+int cddpm_op_add_inplace(cddpm_handle h, float* a_dev, const float* b_dev, int64_t n, void* stream);
+/* weight gradients of the two single-channel convolutions: dw_dev [C][9] = sum_{b,q} act(T)[b,q,c] * s[b, q + sign * tap]
+ * (input conv: T = dL/d(output), s = the image, sign +1; head conv: T = the head's input, act = its GroupNorm + SiLU, s = dL/d(out),
+ * sign -1), and the head's input gradient dact[b,q,c] = sum_tap w9[tap][c] dout[b, q - tap]. */
+int cddpm_op_chan_image_corr(cddpm_handle h, const float* t_dev, const float* coef_dev, int silu, const float* s_dev, int sign, float* dw_dev,
+                             int B, int H, int W, int C, void* stream);
+int cddpm_op_head_dgrad(cddpm_handle h, const float* dout_dev, const float* w9_dev, float* dact_dev, int B, int H, int W, int C, void* stream);
+/* p_losses' loss (cond_DDPM.py:636-645): loss_b_dev[b] = p2w[b] * mean_p |out - target|^(1|2) (their mean is the loss), dout_dev = dL/d(out) */
+int cddpm_op_loss(cddpm_handle h, const float* out_dev, const float* target_dev, const float* w_b_dev, int l2, int B, int HW, float* dout_dev,
+                  float* loss_b_dev, void* stream);
+/* one Adam update (DDPM_2D.py:305-306: lr 1e-4, torch defaults) of a flat parameter vector; step counts from 1 */
+int cddpm_op_adam(cddpm_handle h, float* p_dev, const float* g_dev, float* m_dev, float* v_dev, int64_t n, float lr, float beta1, float beta2,
+                  float eps, int step, void* stream);
 /* backward of a = act(GroupNorm32(x) * (1 + scale) + shift), act = SiLU (silu != 0) or identity (OpenAI_Unet.py:284-338, :325-330):
  * given da_dev [B,HW,C] writes dx_dev [B,HW,C], dgamma_dev / dbeta_dev [C] and, when film_dev ([B][2C] scale | shift) is given,
  * dfilm_dev [B][2C]. The forward statistics are recomputed from x_dev. Everything NHWC fp32. */

@@ -1,0 +1,99 @@
+"""GPU: the training step (host sequencing in training.py, kernels in csrc/train_kernels.hip + the forward
+kernels) against torch autograd through the oracle's UNet in float64 on the same seeded inputs: the loss of p_losses and the gradient of
+every one of the UNet's parameters (reference src/models/modules/cond_DDPM.py:565-655 with autograd; src/models/DDPM_2D.py:114-135),
+then Adam (DDPM_2D.py:305-306)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_pkg
+
+pytestmark = pytest.mark.gpu
+
+
+def _inputs(synth, B, H, W, T, seed):
+    x01 = torch.from_numpy(synth.synth_slices(seed, 0, B, H, W)).reshape(B, 1, H, W)
+    cond = torch.from_numpy(synth.synth_cond(seed, 0, B))
+    noise = torch.from_numpy(synth.noise_xT(seed, 0, B, H, W)).reshape(B, 1, H, W)
+    t = torch.tensor([(137 * (i + 1) + seed) % T for i in range(B)], dtype=torch.long)
+    return x01, cond, noise, t
+
+
+def _reference_loss_and_grads(oracle, sd_np, x01, cond, noise, t, T, objective, loss_type):
+    """float64 autograd through the oracle: the yardstick (fp32 autograd of the reference would carry its own rounding)"""
+    sd = {k: torch.from_numpy(v).double().requires_grad_(True) for k, v in sd_np.items()}
+    buf = oracle.to_float64(oracle.schedule_buffers(T))
+    x0 = x01.double() * 2 - 1
+    xt = oracle.q_sample(x0, t, noise.double(), buf)
+    out = oracle.unet_forward(xt, t, cond.double(), sd)
+    target = noise.double() if objective == "pred_noise" else x0
+    d = out - target
+    per = (d.abs() if loss_type == "l1" else d ** 2).reshape(d.shape[0], -1).mean(dim=1) * buf["p2_loss_weight"][t]
+    loss = per.mean()
+    loss.backward()
+    return float(loss), out.detach(), {k: v.grad for k, v in sd.items()}
+
+
+@pytest.mark.parametrize("B,H,W,objective,loss_type", [(2, 32, 32, "pred_x0", "l1"), (2, 16, 48, "pred_noise", "l2")])
+def test_loss_and_all_gradients_vs_autograd(oracle, synth, sd_np, B, H, W, objective, loss_type):
+    tr = load_pkg("training")
+    T = 1000
+    x01, cond, noise, t = _inputs(synth, B, H, W, T, 3)
+    ref_loss, ref_out, ref_g = _reference_loss_and_grads(oracle, sd_np, x01, cond, noise, t, T, objective, loss_type)
+
+    dev = torch.device("cuda", 0)
+    trainer = tr.UNetTrainer({k: torch.from_numpy(v).to(dev) for k, v in sd_np.items()}, device=dev)
+    buf = load_pkg("schedule").schedule_buffers(T)
+    x0 = x01 * 2 - 1
+    xt = (buf["sqrt_alphas_cumprod"][t].reshape(-1, 1, 1, 1) * x0 + buf["sqrt_one_minus_alphas_cumprod"][t].reshape(-1, 1, 1, 1) * noise)
+    out = trainer.forward(xt.to(dev), t.to(dev), cond.to(dev))
+    assert float((out.double().cpu() - ref_out).abs().max()) < 2e-5
+    target = (noise if objective == "pred_noise" else x0).to(dev)
+    loss, dout = trainer.loss_and_grad(out, target, buf["p2_loss_weight"][t].to(dev).contiguous(), loss_type)
+    assert abs(float(loss) - ref_loss) < 2e-6 * max(1.0, abs(ref_loss))
+    grads = trainer.backward(dout)
+    torch.cuda.synchronize()
+    assert set(grads) == set(ref_g), (set(ref_g) - set(grads), set(grads) - set(ref_g))
+    worst = []
+    for k in sorted(ref_g):
+        r = ref_g[k]
+        g = grads[k].double().cpu().reshape(r.shape)
+        assert torch.isfinite(g).all(), k
+        # error relative to the largest entry of that parameter's gradient; an L1 loss flips sign(out - target) where fp32 and float64
+        # disagree about a pixel that sits on its target, which moves dout by 2/N there: the yardstick carries that ambiguity, the
+        # tolerance absorbs it
+        worst.append((float((g - r).abs().max() / (r.abs().max() + 1e-30)), k))
+    worst.sort(reverse=True)
+    print("worst relative gradient errors:", [(f"{e:.2e}", k) for e, k in worst[:5]])
+    assert worst[0][0] < 2e-4, worst[:5]
+    # the bulk is at fp32 rounding level
+    assert float(np.median([e for e, _ in worst])) < 2e-5
+
+
+def test_adam_update_vs_torch():
+    """cddpm_op_adam against torch.optim.Adam (lr 1e-4, default betas / eps: DDPM_2D.py:305-306) over three steps"""
+    tr = load_pkg("training")
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(0)
+    w0 = torch.randn(4099)
+    ref = torch.nn.Parameter(w0.clone().double())
+    opt = torch.optim.Adam([ref], lr=1e-4)
+    trainer = tr.UNetTrainer({"w": w0.clone()}, device=dev)
+    for step in range(3):
+        gr = torch.randn(4099) * (10.0 ** (step - 1))
+        ref.grad = gr.double()
+        opt.step()
+        trainer.adam_step({"w": gr.to(dev)}, lr=1e-4)
+    got = trainer.p["w"].double().cpu()
+    assert float((got - ref.detach()).abs().max()) < 1e-7
+
+
+def test_training_steps_reduce_the_loss(synth, sd_np):
+    """a few optimisation steps on one fixed batch (same t and noise) lower its loss: forward, loss, backward and Adam compose"""
+    tr = load_pkg("training")
+    dev = torch.device("cuda", 0)
+    trainer = tr.UNetTrainer({k: torch.from_numpy(v).to(dev) for k, v in sd_np.items()}, device=dev)
+    x01, cond, noise, t = _inputs(synth, 2, 32, 32, 1000, 5)
+    losses = [float(tr.training_step(trainer, x01.to(dev), cond.to(dev), t=t.to(dev), noise=noise.to(dev), lr=1e-4)) for _ in range(4)]
+    print("losses", losses)
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0]
