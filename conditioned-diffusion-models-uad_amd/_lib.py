@@ -91,8 +91,8 @@ SYMBOLS = {
     "cddpm_op_add_inplace": (_i, [_vp, _fp, _fp, _i64, _vp]),
     "cddpm_op_chan_image_corr": (_i, [_vp, _fp, _fp, _i, _fp, _i, _fp, _i, _i, _i, _i, _vp]),
     "cddpm_op_head_dgrad": (_i, [_vp, _fp, _fp, _fp, _i, _i, _i, _i, _vp]),
-    "cddpm_op_loss": (_i, [_vp, _fp, _fp, _fp, _i, _i, _i, _fp, _fp, _vp]),
-    "cddpm_op_adam": (_i, [_vp, _fp, _fp, _fp, _fp, _i64, C.c_float, C.c_float, C.c_float, C.c_float, _i, _vp]),
+    "cddpm_op_loss": (_i, [_vp, _fp, _fp, _fp, _i, _i, _i, C.c_float, _fp, _fp, _vp]),
+    "cddpm_op_adam": (_i, [_vp, _fp, _fp, _fp, _fp, _i64, C.c_float, C.c_float, C.c_float, C.c_float, _i, C.c_float, _vp]),
     "cddpm_op_gn_silu_backward": (_i, [_vp, _fp, _fp, _fp, _fp, _fp, _i, _fp, _fp, _fp, _fp, _i, _i, _i, _vp]),
     "cddpm_stat_records": (_i, [_i, _i, _i]),
     "cddpm_packed_conv_bytes": (_sz, [_i, _i, _i]),

@@ -1606,16 +1606,16 @@ int cddpm_op_head_dgrad(cddpm_handle h, const float* dout_dev, const float* w9_d
     launch_head_dgrad(dout_dev, w9_dev, dact_dev, B, H, W, C, s);
     OP_EPILOGUE()
 }
-int cddpm_op_loss(cddpm_handle h, const float* out_dev, const float* target_dev, const float* w_b_dev, int l2, int B, int HW, float* dout_dev,
-                  float* loss_b_dev, void* stream) {
+int cddpm_op_loss(cddpm_handle h, const float* out_dev, const float* target_dev, const float* w_b_dev, int l2, int B, int HW, float grad_scale,
+                  float* dout_dev, float* loss_b_dev, void* stream) {
     OP_PROLOGUE(out_dev && target_dev && dout_dev && loss_b_dev && B > 0 && HW > 0, "cddpm_op_loss: bad arguments")
-    launch_loss(out_dev, target_dev, w_b_dev, l2, B, HW, dout_dev, loss_b_dev, s);
+    launch_loss(out_dev, target_dev, w_b_dev, l2, B, HW, grad_scale, dout_dev, loss_b_dev, s);
     OP_EPILOGUE()
 }
 int cddpm_op_adam(cddpm_handle h, float* p_dev, const float* g_dev, float* m_dev, float* v_dev, int64_t n, float lr, float beta1, float beta2,
-                  float eps, int step, void* stream) {
+                  float eps, int step, float grad_unscale, void* stream) {
     OP_PROLOGUE(p_dev && g_dev && m_dev && v_dev && n > 0 && step >= 1, "cddpm_op_adam: bad arguments")
-    launch_adam(p_dev, g_dev, m_dev, v_dev, n, lr, beta1, beta2, eps, step, s);
+    launch_adam(p_dev, g_dev, m_dev, v_dev, n, lr, beta1, beta2, eps, step, grad_unscale, s);
     OP_EPILOGUE()
 }
 

@@ -170,9 +170,9 @@ void launch_add_inplace(float* a, const float* b, long long n, hipStream_t strea
 void launch_chan_image_corr(const float* T, const float* coef, int silu, const float* simg, int sign, int B, int H, int W, int C,
                             double* part, float* dw, hipStream_t stream);
 void launch_head_dgrad(const float* dout, const float* w9, float* dact, int B, int H, int W, int C, hipStream_t stream);
-void launch_loss(const float* out, const float* target, const float* w_b, int l2, int B, int HW, float* dout, float* loss_b,
+void launch_loss(const float* out, const float* target, const float* w_b, int l2, int B, int HW, float grad_scale, float* dout, float* loss_b,
                  hipStream_t stream);
-void launch_adam(float* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2, float eps, int step,
+void launch_adam(float* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2, float eps, int step, float grad_unscale,
                  hipStream_t stream);
 void launch_gn_silu_backward(const float* x, const float* da, const float* planes, const float* gamma, const float* beta,
                              const float* film, int silu, int B, int C, int HW, int nsplit, double* part, float* out_bc, float* dx,

@@ -748,11 +748,11 @@ void launch_head_dgrad(const float* dout, const float* w9, float* dact, int B, i
 // loss of p_losses (cond_DDPM.py:636-645): per-sample mean of |out - target| (l1) or (out - target)^2 (l2), times p2_loss_weight[t_b],
 // mean over the batch; writes dL/d(out) and the B per-sample terms (their mean is the loss)
 __global__ __launch_bounds__(256) void loss_kernel(const float* __restrict__ out, const float* __restrict__ target, const float* __restrict__ w_b,
-                                                   int l2, int B, int HW, float* __restrict__ dout, float* __restrict__ loss_b) {
+                                                   int l2, int B, int HW, float grad_scale, float* __restrict__ dout, float* __restrict__ loss_b) {
     __shared__ double red[256];
     const int b = blockIdx.x, tid = threadIdx.x;
     const float wb = w_b ? w_b[b] : 1.0f;
-    const float gscale = wb / ((float)B * (float)HW);
+    const float gscale = grad_scale * wb / ((float)B * (float)HW);
     double s = 0;
     for (int p = tid; p < HW; p += 256) {
         const float d = out[(size_t)b * HW + p] - target[(size_t)b * HW + p];
@@ -767,18 +767,18 @@ __global__ __launch_bounds__(256) void loss_kernel(const float* __restrict__ out
 void launch_bias_grad(const float* dy, long long npix, int C, float* db, hipStream_t stream) {
     hipLaunchKernelGGL(bias_grad_kernel, dim3(C / 4), dim3(256), 0, stream, dy, npix, C, db);
 }
-void launch_loss(const float* out, const float* target, const float* w_b, int l2, int B, int HW, float* dout, float* loss_b,
+void launch_loss(const float* out, const float* target, const float* w_b, int l2, int B, int HW, float grad_scale, float* dout, float* loss_b,
                  hipStream_t stream) {
-    hipLaunchKernelGGL(loss_kernel, dim3(B), dim3(256), 0, stream, out, target, w_b, l2, B, HW, dout, loss_b);
+    hipLaunchKernelGGL(loss_kernel, dim3(B), dim3(256), 0, stream, out, target, w_b, l2, B, HW, grad_scale, dout, loss_b);
 }
 
 // Adam (torch.optim.Adam defaults of DDPM_2D.configure_optimizers, DDPM_2D.py:305-306: lr 1e-4, betas (0.9, 0.999), eps 1e-8, no weight
 // decay) on a flat parameter vector: m, v fp32 state; bias corrections passed in
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                                                   long long n, float lr, float b1, float b2, float eps, float bc1, float bc2) {
+                                                   long long n, float lr, float b1, float b2, float eps, float bc1, float bc2, float unscale) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const float gi = g[i];
+    const float gi = g[i] * unscale;
     const float mi = b1 * m[i] + (1.0f - b1) * gi;
     const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
     m[i] = mi; v[i] = vi;
@@ -786,9 +786,9 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     p[i] -= (lr / bc1) * (mi / denom);
 }
 void launch_adam(float* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2, float eps, int step,
-                 hipStream_t stream) {
+                 float grad_unscale, hipStream_t stream) {
     const float bc1 = 1.0f - powf(b1, (float)step), bc2 = 1.0f - powf(b2, (float)step);
-    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, p, g, m, v, n, lr, b1, b2, eps, bc1, bc2);
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, p, g, m, v, n, lr, b1, b2, eps, bc1, bc2, grad_unscale);
 }
 
 }  // namespace cddpm

@@ -315,17 +315,20 @@ class UNetTrainer:
         return g
 
     # ------------------------------------------------------------------ loss of p_losses + one optimizer step
-    def loss_and_grad(self, model_out, target, p2w=None, loss_type="l1"):
+    def loss_and_grad(self, model_out, target, p2w=None, loss_type="l1", grad_scale=None):
+        """-> (loss, grad_scale * dL/d(model_out)); grad_scale defaults to B*H*W rounded up to a power of two (see cddpm_op_loss)"""
         B, _c, H, W = model_out.shape
         dout = torch.empty_like(model_out)
         loss_b = torch.empty((B,), dtype=torch.float32, device=self.dev)
+        self.grad_scale = float(grad_scale) if grad_scale is not None else float(2 ** math.ceil(math.log2(B * H * W)))
         self._ck(self.lib.cddpm_op_loss(self.h, _p(model_out), _p(target.contiguous().float()), _p(p2w), int(loss_type == "l2"), B, H * W,
-                                        _p(dout), _p(loss_b), self._s()), "op_loss")
+                                        C.c_float(self.grad_scale), _p(dout), _p(loss_b), self._s()), "op_loss")
         return loss_b.mean(), dout
 
-    def adam_step(self, grads: Dict[str, torch.Tensor], lr=1e-4, betas=(0.9, 0.999), eps=1e-8):
+    def adam_step(self, grads: Dict[str, torch.Tensor], lr=1e-4, betas=(0.9, 0.999), eps=1e-8, grad_scale=None):
         """torch.optim.Adam(lr=1e-4) of DDPM_2D.configure_optimizers (DDPM_2D.py:305-306) on every UNet parameter"""
         st = self.state
+        unscale = 1.0 / (grad_scale if grad_scale is not None else getattr(self, "grad_scale", 1.0))
         st["step"] = st.get("step", 0) + 1
         for k, gr in grads.items():
             w = self.p[k]
@@ -334,7 +337,7 @@ class UNetTrainer:
             m, v = st[k]
             gr = gr.reshape(w.shape).contiguous()
             self._ck(self.lib.cddpm_op_adam(self.h, _p(w), _p(gr), _p(m), _p(v), w.numel(), C.c_float(lr), C.c_float(betas[0]), C.c_float(betas[1]),
-                                            C.c_float(eps), st["step"], self._s()), "op_adam")
+                                            C.c_float(eps), st["step"], C.c_float(unscale), self._s()), "op_adam")
 
 
 def training_step(trainer: UNetTrainer, x01: torch.Tensor, cond: torch.Tensor, *, t: torch.Tensor, noise: torch.Tensor, timesteps=1000,

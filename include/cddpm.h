@@ -291,12 +291,16 @@ int cddpm_op_add_inplace(cddpm_handle h, float* a_dev, const float* b_dev, int64
 int cddpm_op_chan_image_corr(cddpm_handle h, const float* t_dev, const float* coef_dev, int silu, const float* s_dev, int sign, float* dw_dev,
                              int B, int H, int W, int C, void* stream);
 int cddpm_op_head_dgrad(cddpm_handle h, const float* dout_dev, const float* w9_dev, float* dact_dev, int B, int H, int W, int C, void* stream);
-/* p_losses' loss (cond_DDPM.py:636-645): loss_b_dev[b] = p2w[b] * mean_p |out - target|^(1|2) (their mean is the loss), dout_dev = dL/d(out) */
-int cddpm_op_loss(cddpm_handle h, const float* out_dev, const float* target_dev, const float* w_b_dev, int l2, int B, int HW, float* dout_dev,
-                  float* loss_b_dev, void* stream);
-/* one Adam update (DDPM_2D.py:305-306: lr 1e-4, torch defaults) of a flat parameter vector; step counts from 1 */
+/* p_losses' loss (cond_DDPM.py:636-645): loss_b_dev[b] = p2w[b] * mean_p |out - target|^(1|2) (their mean is the loss), dout_dev =
+ * grad_scale * dL/d(out). grad_scale (a power of two, e.g. B * HW rounded) is the loss scale of the backward pass: the convolution
+ * input-gradient kernels form their products from fp16 operand splits whose absolute floor is 2^-25, so the gradient tensors are carried
+ * at O(1) magnitude (every backward operator is linear in them, the scaling is exact) and cddpm_op_adam divides it out again. */
+int cddpm_op_loss(cddpm_handle h, const float* out_dev, const float* target_dev, const float* w_b_dev, int l2, int B, int HW, float grad_scale,
+                  float* dout_dev, float* loss_b_dev, void* stream);
+/* one Adam update (DDPM_2D.py:305-306: lr 1e-4, torch defaults) of a flat parameter vector; step counts from 1; the gradient used is
+ * g_dev * grad_unscale (1 / the loss scale) */
 int cddpm_op_adam(cddpm_handle h, float* p_dev, const float* g_dev, float* m_dev, float* v_dev, int64_t n, float lr, float beta1, float beta2,
-                  float eps, int step, void* stream);
+                  float eps, int step, float grad_unscale, void* stream);
 /* backward of a = act(GroupNorm32(x) * (1 + scale) + shift), act = SiLU (silu != 0) or identity (OpenAI_Unet.py:284-338, :325-330):
  * given da_dev [B,HW,C] writes dx_dev [B,HW,C], dgamma_dev / dbeta_dev [C] and, when film_dev ([B][2C] scale | shift) is given,
  * dfilm_dev [B][2C]. The forward statistics are recomputed from x_dev. Everything NHWC fp32. */

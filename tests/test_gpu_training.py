@@ -19,55 +19,64 @@ def _inputs(synth, B, H, W, T, seed):
     return x01, cond, noise, t
 
 
-def _reference_loss_and_grads(oracle, sd_np, x01, cond, noise, t, T, objective, loss_type):
-    """float64 autograd through the oracle: the yardstick (fp32 autograd of the reference would carry its own rounding)"""
-    sd = {k: torch.from_numpy(v).double().requires_grad_(True) for k, v in sd_np.items()}
-    buf = oracle.to_float64(oracle.schedule_buffers(T))
-    x0 = x01.double() * 2 - 1
-    xt = oracle.q_sample(x0, t, noise.double(), buf)
-    out = oracle.unet_forward(xt, t, cond.double(), sd)
-    target = noise.double() if objective == "pred_noise" else x0
+def _loss_of(out, target, p2w, loss_type):
     d = out - target
-    per = (d.abs() if loss_type == "l1" else d ** 2).reshape(d.shape[0], -1).mean(dim=1) * buf["p2_loss_weight"][t]
-    loss = per.mean()
-    loss.backward()
-    return float(loss), out.detach(), {k: v.grad for k, v in sd.items()}
+    per = (d.abs() if loss_type == "l1" else d ** 2).reshape(d.shape[0], -1).mean(dim=1) * p2w
+    return per.mean()
 
 
 @pytest.mark.parametrize("B,H,W,objective,loss_type", [(2, 32, 32, "pred_x0", "l1"), (2, 16, 48, "pred_noise", "l2")])
 def test_loss_and_all_gradients_vs_autograd(oracle, synth, sd_np, B, H, W, objective, loss_type):
+    """Yardstick: float64 autograd through the oracle's UNet. The L1 loss's derivative sign(out - target) is discontinuous, so the chain
+    is checked in two links that share no ambiguity: (1) loss and dL/d(out) from the HIP loss kernel against autograd of the loss formula
+    AT the HIP forward's own output; (2) the HIP backward against the oracle's vector-Jacobian product for that same dL/d(out)."""
     tr = load_pkg("training")
     T = 1000
     x01, cond, noise, t = _inputs(synth, B, H, W, T, 3)
-    ref_loss, ref_out, ref_g = _reference_loss_and_grads(oracle, sd_np, x01, cond, noise, t, T, objective, loss_type)
+    sd = {k: torch.from_numpy(v).double().requires_grad_(True) for k, v in sd_np.items()}
+    buf64 = oracle.to_float64(oracle.schedule_buffers(T))
+    x0 = x01 * 2 - 1
+    ref_out = oracle.unet_forward(oracle.q_sample(x0.double(), t, noise.double(), buf64), t, cond.double(), sd)
+    target = noise if objective == "pred_noise" else x0
+    ref_loss = float(_loss_of(ref_out.detach(), target.double(), buf64["p2_loss_weight"][t], loss_type))
 
     dev = torch.device("cuda", 0)
     trainer = tr.UNetTrainer({k: torch.from_numpy(v).to(dev) for k, v in sd_np.items()}, device=dev)
     buf = load_pkg("schedule").schedule_buffers(T)
-    x0 = x01 * 2 - 1
     xt = (buf["sqrt_alphas_cumprod"][t].reshape(-1, 1, 1, 1) * x0 + buf["sqrt_one_minus_alphas_cumprod"][t].reshape(-1, 1, 1, 1) * noise)
     out = trainer.forward(xt.to(dev), t.to(dev), cond.to(dev))
-    assert float((out.double().cpu() - ref_out).abs().max()) < 2e-5
-    target = (noise if objective == "pred_noise" else x0).to(dev)
-    loss, dout = trainer.loss_and_grad(out, target, buf["p2_loss_weight"][t].to(dev).contiguous(), loss_type)
+    assert float((out.double().cpu() - ref_out.detach()).abs().max()) < 2e-5
+    # link 1: the loss kernel
+    loss, dout = trainer.loss_and_grad(out, target.to(dev), buf["p2_loss_weight"][t].to(dev).contiguous(), loss_type)
     assert abs(float(loss) - ref_loss) < 2e-6 * max(1.0, abs(ref_loss))
+    o64 = out.double().cpu().requires_grad_(True)
+    _loss_of(o64, target.double(), buf64["p2_loss_weight"][t], loss_type).backward()
+    S = trainer.grad_scale            # the loss scale of the backward pass (a power of two: exact)
+    assert S == 2 ** round(np.log2(S)) and S >= B * H * W
+    assert float((dout.double().cpu() / S - o64.grad).abs().max()) <= 1e-6 * float(o64.grad.abs().max())
+    # link 2: the backward pass
     grads = trainer.backward(dout)
     torch.cuda.synchronize()
+    ref_out.backward(dout.double().cpu() / S)
+    ref_g = {k: v.grad for k, v in sd.items()}
     assert set(grads) == set(ref_g), (set(ref_g) - set(grads), set(grads) - set(ref_g))
     worst = []
     for k in sorted(ref_g):
         r = ref_g[k]
-        g = grads[k].double().cpu().reshape(r.shape)
+        g = grads[k].double().cpu().reshape(r.shape) / S
         assert torch.isfinite(g).all(), k
-        # error relative to the largest entry of that parameter's gradient; an L1 loss flips sign(out - target) where fp32 and float64
-        # disagree about a pixel that sits on its target, which moves dout by 2/N there: the yardstick carries that ambiguity, the
-        # tolerance absorbs it
-        worst.append((float((g - r).abs().max() / (r.abs().max() + 1e-30)), k))
+        worst.append((float((g - r).abs().max() / (r.abs().max() + 1e-30)), k))   # relative to the parameter's largest gradient entry
+    import os
+    if os.environ.get("CDDPM_GRAD_REPORT"):
+        with open(os.environ["CDDPM_GRAD_REPORT"] + f".{loss_type}", "w") as f:
+            for _kind, name, _a in trainer.program:
+                for e, k in worst:
+                    if k.startswith(name + "."):
+                        f.write(f"{e:.3e} {k}\n")
     worst.sort(reverse=True)
-    print("worst relative gradient errors:", [(f"{e:.2e}", k) for e, k in worst[:5]])
-    assert worst[0][0] < 2e-4, worst[:5]
-    # the bulk is at fp32 rounding level
-    assert float(np.median([e for e, _ in worst])) < 2e-5
+    print("worst relative gradient errors:", [(f"{e:.2e}", k) for e, k in worst[:5]], "median", float(np.median([e for e, _ in worst])))
+    assert worst[0][0] < 1e-4, worst[:5]
+    assert float(np.median([e for e, _ in worst])) < 1e-5
 
 
 def test_adam_update_vs_torch():
@@ -85,7 +94,7 @@ def test_adam_update_vs_torch():
         opt.step()
         trainer.adam_step({"w": gr.to(dev)}, lr=1e-4)
     got = trainer.p["w"].double().cpu()
-    assert float((got - ref.detach()).abs().max()) < 1e-7
+    assert float((got - ref.detach()).abs().max()) < 1e-6      # fp32 master weights of magnitude ~1 against a float64 optimizer
 
 
 def test_training_steps_reduce_the_loss(synth, sd_np):
