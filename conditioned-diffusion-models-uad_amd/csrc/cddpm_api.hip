@@ -62,6 +62,9 @@ thread_local std::string g_create_error;
 struct cddpm_ctx {
     cddpm_unet_desc d;
     int device = 0;
+    void* arena = nullptr;            // scratch of the standalone operators (cddpm_op_set_scratch); nullptr: hipMalloc per call
+    size_t arena_bytes = 0;
+    float* zero_bias = nullptr;       // 4096 zeros: the bias of an operator called without one
     std::string err;
     bool weights_loaded = false, schedule_set = false;
     int cond_B = -1;
@@ -745,6 +748,49 @@ int forward_impl(cddpm_ctx* h, const float* x, float* out, int B, int H, int W, 
 // ================================================================================================
 // C ABI
 // ================================================================================================
+// ---- temporaries and parameters of the standalone operators ------------------------------------------------------------------
+// Temporaries come from the handle's scratch arena when cddpm_op_set_scratch gave it one (re-used from its start by every call: calls
+// on ONE stream are ordered, nothing synchronises -- what the training step runs on); without an arena they are hipMalloc'ed for the
+// call and freed after a stream synchronisation (the kernel tests).
+struct OpScratch {
+    cddpm_ctx* h;
+    hipStream_t s;
+    std::vector<void*> owned;
+    size_t off = 0;
+    bool failed = false;
+    OpScratch(cddpm_ctx* h_, hipStream_t s_) : h(h_), s(s_) {}
+    void* get(size_t bytes) {
+        bytes = (bytes + 255) & ~(size_t)255;
+        if (h->arena) {
+            if (off + bytes > h->arena_bytes) { failed = true; off += bytes; return nullptr; }
+            void* p = static_cast<char*>(h->arena) + off;
+            off += bytes;
+            return p;
+        }
+        void* p = nullptr;
+        if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); failed = true; return nullptr; }
+        owned.push_back(p);
+        return p;
+    }
+    template <class T> T* n(size_t count) { return static_cast<T*>(get(count * sizeof(T))); }
+    // a parameter vector given in host OR device memory: device pointers are used where they lie, host ones are staged
+    const float* param(const float* p, size_t count) {
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, p) == hipSuccess && at.type == hipMemoryTypeDevice) return p;
+        (void)hipGetLastError();
+        float* d = n<float>(count);
+        if (d && hipMemcpyAsync(d, p, count * sizeof(float), hipMemcpyHostToDevice, s) != hipSuccess) failed = true;
+        return d;
+    }
+    ~OpScratch() {
+        if (owned.empty()) return;
+        (void)hipStreamSynchronize(s);
+        for (void* p : owned) (void)hipFree(p);
+    }
+};
+#define SCRATCH_CHECK(sc)                                                                                                   \
+    if ((sc).failed) return fail(h, "operator scratch: %zu bytes needed, arena holds %zu (cddpm_op_set_scratch)", (sc).off, h->arena_bytes);
+
 extern "C" {
 
 const char* cddpm_last_error(cddpm_handle h) { return h ? h->err.c_str() : g_create_error.c_str(); }
@@ -804,6 +850,8 @@ void cddpm_destroy(cddpm_handle h) {
     if (h->gev_out) (void)hipEventDestroy(h->gev_out);
     if (h->gstream) (void)hipStreamDestroy(h->gstream);
     for (void* p : h->allocs) (void)hipFree(p);
+    if (h->arena) (void)hipFree(h->arena);
+    if (h->zero_bias) (void)hipFree(h->zero_bias);
     { hipEvent_t shared = nullptr;
       for (auto& r : h->prof) { if (r.a != shared) (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); shared = r.b; } }
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
@@ -1231,6 +1279,73 @@ int cddpm_get_profile(cddpm_handle h, int ncls, double* ms, double* flops, doubl
     return 0;
 }
 
+int cddpm_op_set_scratch(cddpm_handle h, size_t bytes) {
+    if (!h) return -1;
+    HIPCHECK(h, hipSetDevice(h->device));
+    HIPCHECK(h, hipDeviceSynchronize());
+    if (h->arena) { (void)hipFree(h->arena); h->arena = nullptr; h->arena_bytes = 0; }
+    if (bytes) { HIPCHECK(h, hipMalloc(&h->arena, bytes)); h->arena_bytes = bytes; }
+    return 0;
+}
+
+static int need_zero_bias(cddpm_ctx* h) {
+    if (h->zero_bias) return 0;
+    HIPCHECK(h, hipMalloc((void**)&h->zero_bias, 4096 * sizeof(float)));
+    HIPCHECK(h, hipMemset(h->zero_bias, 0, 4096 * sizeof(float)));
+    return 0;
+}
+
+int cddpm_op_absmax(cddpm_handle h, const float* x_dev, int64_t n, float* out_dev, void* stream) {
+    if (!h) return -1;
+    if (!x_dev || !out_dev || n < 1) return fail(h, "cddpm_op_absmax: bad arguments");
+    HIPCHECK(h, hipSetDevice(h->device));
+    launch_absmax(x_dev, n, out_dev, (hipStream_t)stream);
+    HIPCHECK(h, hipGetLastError());
+    return 0;
+}
+
+int cddpm_op_pack_conv(cddpm_handle h, const float* w_dev, int Cout, int Cin, int ksize, int mode, int scale_exp, void* packed_dev,
+                       void* stream) {
+    if (!h) return -1;
+    if (conv_mode() != 2) return fail(h, "cddpm_op_pack_conv: the device packer serves the default convolution family (CDDPM_CONV=h3) only");
+    // O / I: output / input channels of the PACKED operator (mode 1 swaps the roles of the forward tensor's dimensions)
+    const int O = mode == 1 ? Cin : Cout, I = mode == 1 ? Cout : Cin;
+    if (!w_dev || !packed_dev || (ksize != 1 && ksize != 3) || mode < 0 || mode > 2 || (mode == 2 && ksize != 3) || O <= 0 || I <= 0 ||
+        O % 128 || I % 32 || scale_exp < 0 || scale_exp > 24)
+        return fail(h, "cddpm_op_pack_conv: unsupported arguments (Cout %d, Cin %d, k %d, mode %d, exponent %d)", Cout, Cin, ksize, mode, scale_exp);
+    HIPCHECK(h, hipSetDevice(h->device));
+    launch_pack_conv_split(w_dev, O, I, mode == 2 ? 4 : ksize * ksize, mode, scale_exp, packed_dev, (hipStream_t)stream);
+    HIPCHECK(h, hipGetLastError());
+    return 0;
+}
+
+int cddpm_op_conv_packed(cddpm_handle h, const float* src0, int C0, const float* src1, int C1, const float* coef_dev, int silu, int folded_up,
+                         const void* packed_dev, int scale_exp, const float* bias_dev, int Cout, int ksize, const float* res_dev,
+                         int res_upsample, const float* skip_dev, int S0, const void* skip_packed_dev, float* out_dev, int B, int H, int W,
+                         void* stream) {
+    if (!h) return -1;
+    const int Cin = C0 + C1;
+    if (conv_mode() != 2) return fail(h, "cddpm_op_conv_packed: default convolution family (CDDPM_CONV=h3) only");
+    if ((ksize != 1 && ksize != 3) || C0 <= 0 || C0 % 32 || C1 < 0 || C1 % 32 || Cout <= 0 || Cout % 128 || Cout > 4096 || B < 1 || H < 1 || W < 1 ||
+        (folded_up && (ksize != 3 || C1 || H % 2 || W % 2)) || (skip_dev && (S0 <= 0 || S0 % 32 || !skip_packed_dev || ksize != 3)) ||
+        (C1 && !src1) || scale_exp < 0 || scale_exp > 24)
+        return fail(h, "cddpm_op_conv_packed: unsupported shape (k %d, C0 %d, C1 %d, Cout %d, S0 %d)", ksize, C0, C1, Cout, S0);
+    if (!src0 || !packed_dev || !out_dev) return fail(h, "cddpm_op_conv_packed: NULL argument");
+    HIPCHECK(h, hipSetDevice(h->device));
+    if (!bias_dev) { if (need_zero_bias(h)) return -1; bias_dev = h->zero_bias; }
+    ConvArgs a;
+    zero_conv_args(a);
+    a.src0 = src0; a.C0 = C0; a.src1 = src1; a.C1 = C1;
+    a.srcH = folded_up ? H / 2 : H; a.srcW = folded_up ? W / 2 : W;
+    a.coef = coef_dev; a.silu = silu; a.wpk = static_cast<const float*>(packed_dev); a.bias = bias_dev; a.res = res_dev; a.res_up = res_upsample;
+    a.skip0 = skip_dev; a.S0 = skip_dev ? S0 : 0; a.skip_wpk = static_cast<const float*>(skip_packed_dev);
+    a.wscale_inv = ldexpf(1.0f, -scale_exp);
+    a.out = out_dev; a.B = B; a.H = H; a.W = W; a.Cout = Cout; a.taps = folded_up ? 4 : ksize * ksize;
+    launch_conv(a, (hipStream_t)stream);
+    HIPCHECK(h, hipGetLastError());
+    return 0;
+}
+
 // ---- standalone ops for kernel tests ---------------------------------------------------------------
 int cddpm_op_conv(cddpm_handle h, const float* src0, int C0, const float* src1, int C1, const float* coef_dev, int silu,
                   int upsample, const float* w_host, const float* bias_host, int Cout, int ksize, const float* res_dev,
@@ -1419,23 +1534,17 @@ int cddpm_op_gn_coef(cddpm_handle h, const float* src0, int C0, const float* src
     hipStream_t s = (hipStream_t)stream;
     HIPCHECK(h, hipSetDevice(h->device));
     const int ns = gn_nsplit(B, HW);
-    float *rec0 = nullptr, *rec1 = nullptr, *g = nullptr, *bt = nullptr;
-    HIPCHECK(h, hipMalloc((void**)&rec0, (size_t)B * ns * C0 * 2 * sizeof(float)));
-    if (src1) HIPCHECK(h, hipMalloc((void**)&rec1, (size_t)B * ns * C1 * 2 * sizeof(float)));
-    HIPCHECK(h, hipMalloc((void**)&g, (size_t)C * sizeof(float)));
-    HIPCHECK(h, hipMalloc((void**)&bt, (size_t)C * sizeof(float)));
-    HIPCHECK(h, hipMemcpy(g, gamma_host, (size_t)C * sizeof(float), hipMemcpyHostToDevice));
-    HIPCHECK(h, hipMemcpy(bt, beta_host, (size_t)C * sizeof(float), hipMemcpyHostToDevice));
+    OpScratch sc(h, s);
+    float* rec0 = sc.n<float>((size_t)B * ns * C0 * 2);
+    float* rec1 = src1 ? sc.n<float>((size_t)B * ns * C1 * 2) : nullptr;
+    const float* g = sc.param(gamma_host, C);
+    const float* bt = sc.param(beta_host, C);
+    SCRATCH_CHECK(sc)
     launch_gn_partial(src0, C0, B, HW, ns, rec0, s);
     if (src1) launch_gn_partial(src1, C1, B, HW, ns, rec1, s);
     launch_gn_finalize(rec0, C0, ns, rec1, C1, src1 ? ns : 0, B, HW, g, bt, nullptr, nullptr, 0, 0, nullptr, film_dev,
                        coef_dev, s);
     HIPCHECK(h, hipGetLastError());
-    HIPCHECK(h, hipStreamSynchronize(s));
-    (void)hipFree(rec0);
-    if (rec1) (void)hipFree(rec1);
-    (void)hipFree(g);
-    (void)hipFree(bt);
     return 0;
 }
 
@@ -1496,12 +1605,11 @@ int cddpm_op_conv_wgrad(cddpm_handle h, const float* x0_dev, int C0, const float
     hipStream_t s = (hipStream_t)stream;
     HIPCHECK(h, hipSetDevice(h->device));
     const int P = conv_wgrad_parts(B, H, W, Cin, Cout, taps);
-    float* part = nullptr;
-    HIPCHECK(h, hipMalloc((void**)&part, (size_t)P * Cout * Cin * taps * sizeof(float)));
+    OpScratch sc(h, s);
+    float* part = sc.n<float>((size_t)P * Cout * Cin * taps);
+    SCRATCH_CHECK(sc)
     launch_conv_wgrad(x0_dev, C0, x1_dev, C1, coef_dev, silu, upsample ? 1 : 0, dy_dev, B, H, W, Cout, taps, part, P, dw_dev, db_dev, s);
     HIPCHECK(h, hipGetLastError());
-    HIPCHECK(h, hipStreamSynchronize(s));
-    (void)hipFree(part);
     return 0;
 }
 
@@ -1513,13 +1621,11 @@ int cddpm_op_attention_backward(cddpm_handle h, const float* qkv_dev, const floa
     hipStream_t s = (hipStream_t)stream;
     HIPCHECK(h, hipSetDevice(h->device));
     const size_t nn = (size_t)B * (C / 64) * N * N;
-    float *p = nullptr, *dp = nullptr;
-    HIPCHECK(h, hipMalloc((void**)&p, nn * sizeof(float)));
-    HIPCHECK(h, hipMalloc((void**)&dp, nn * sizeof(float)));
+    OpScratch sc(h, s);
+    float *p = sc.n<float>(nn), *dp = sc.n<float>(nn);
+    SCRATCH_CHECK(sc)
     launch_attention_backward(qkv_dev, da_dev, dqkv_dev, p, dp, B, N, C, s);
     HIPCHECK(h, hipGetLastError());
-    HIPCHECK(h, hipStreamSynchronize(s));
-    (void)hipFree(p); (void)hipFree(dp);
     return 0;
 }
 
@@ -1529,12 +1635,11 @@ int cddpm_op_linear_backward(cddpm_handle h, const float* x_dev, const float* w_
     if (M < 1 || N < 1 || K < 1 || !x_dev || !w_dev || !dy_dev || !dw_dev) return fail(h, "cddpm_op_linear_backward: bad arguments");
     hipStream_t s = (hipStream_t)stream;
     HIPCHECK(h, hipSetDevice(h->device));
-    float* a = nullptr;
-    if (silu_in) HIPCHECK(h, hipMalloc((void**)&a, (size_t)M * K * sizeof(float)));
+    OpScratch sc(h, s);
+    float* a = silu_in ? sc.n<float>((size_t)M * K) : nullptr;
+    SCRATCH_CHECK(sc)
     launch_linear_backward(x_dev, w_dev, dy_dev, M, N, K, silu_in, a, dw_dev, db_dev, dx_dev, s);
     HIPCHECK(h, hipGetLastError());
-    HIPCHECK(h, hipStreamSynchronize(s));
-    if (a) (void)hipFree(a);
     return 0;
 }
 
@@ -1562,12 +1667,11 @@ int cddpm_op_conv_in1(cddpm_handle h, const float* x_dev, const float* w_dev, co
 int cddpm_op_head(cddpm_handle h, const float* x_dev, const float* coef_dev, const float* w9_dev, float bias, float* out_dev, int B,
                   int H, int W, int C, void* stream) {
     OP_PROLOGUE(x_dev && coef_dev && w9_dev && out_dev && C % 32 == 0, "cddpm_op_head: bad arguments")
-    float* P = nullptr;
-    HIPCHECK(h, hipMalloc((void**)&P, (size_t)B * H * W * 9 * sizeof(float)));
+    OpScratch sc(h, s);
+    float* P = sc.n<float>((size_t)B * H * W * 9);
+    SCRATCH_CHECK(sc)
     launch_head_dots(x_dev, coef_dev, w9_dev, P, B, H * W, C, s);
     launch_head_gather(P, bias, out_dev, B, H, W, s);
-    HIPCHECK(h, hipStreamSynchronize(s));
-    (void)hipFree(P);
     OP_EPILOGUE()
 }
 int cddpm_op_pool_act(cddpm_handle h, const float* x_dev, const float* coef_dev, float* hp_dev, float* xp_dev, int B, int H, int W, int C,
@@ -1594,11 +1698,10 @@ int cddpm_op_add_inplace(cddpm_handle h, float* a_dev, const float* b_dev, int64
 int cddpm_op_chan_image_corr(cddpm_handle h, const float* t_dev, const float* coef_dev, int silu, const float* s_dev, int sign, float* dw_dev,
                              int B, int H, int W, int C, void* stream) {
     OP_PROLOGUE(t_dev && s_dev && dw_dev && C % 64 == 0 && (sign == 1 || sign == -1), "cddpm_op_chan_image_corr: bad arguments")
-    double* part = nullptr;
-    HIPCHECK(h, hipMalloc((void**)&part, (size_t)64 * C * 9 * sizeof(double)));
+    OpScratch sc(h, s);
+    double* part = sc.n<double>((size_t)64 * C * 9);
+    SCRATCH_CHECK(sc)
     launch_chan_image_corr(t_dev, coef_dev, silu, s_dev, sign, B, H, W, C, part, dw_dev, s);
-    HIPCHECK(h, hipStreamSynchronize(s));
-    (void)hipFree(part);
     OP_EPILOGUE()
 }
 int cddpm_op_head_dgrad(cddpm_handle h, const float* dout_dev, const float* w9_dev, float* dact_dev, int B, int H, int W, int C, void* stream) {
@@ -1629,23 +1732,19 @@ int cddpm_op_gn_silu_backward(cddpm_handle h, const float* x_dev, const float* d
     hipStream_t s = (hipStream_t)stream;
     HIPCHECK(h, hipSetDevice(h->device));
     const int ns = gn_nsplit(B, HW);
-    float *rec = nullptr, *g = nullptr, *bt = nullptr, *planes = nullptr, *out_bc = nullptr;
-    double* part = nullptr;
-    HIPCHECK(h, hipMalloc((void**)&rec, (size_t)B * ns * C * 2 * sizeof(float)));
-    HIPCHECK(h, hipMalloc((void**)&g, (size_t)C * sizeof(float)));
-    HIPCHECK(h, hipMalloc((void**)&bt, (size_t)C * sizeof(float)));
-    HIPCHECK(h, hipMalloc((void**)&planes, (size_t)4 * B * C * sizeof(float)));
-    HIPCHECK(h, hipMalloc((void**)&out_bc, (size_t)4 * B * C * sizeof(float)));
-    HIPCHECK(h, hipMalloc((void**)&part, (size_t)B * ns * C * 2 * sizeof(double)));
-    HIPCHECK(h, hipMemcpy(g, gamma_host, (size_t)C * sizeof(float), hipMemcpyHostToDevice));
-    HIPCHECK(h, hipMemcpy(bt, beta_host, (size_t)C * sizeof(float), hipMemcpyHostToDevice));
+    OpScratch sc(h, s);
+    float* rec = sc.n<float>((size_t)B * ns * C * 2);
+    const float* g = sc.param(gamma_host, C);
+    const float* bt = sc.param(beta_host, C);
+    float* planes = sc.n<float>((size_t)4 * B * C);
+    float* out_bc = sc.n<float>((size_t)4 * B * C);
+    double* part = sc.n<double>((size_t)B * ns * C * 2);
+    SCRATCH_CHECK(sc)
     launch_gn_partial(x_dev, C, B, HW, ns, rec, s);
     launch_gn_bwd_planes(rec, ns, g, bt, film_dev, B, C, HW, planes, s);
     launch_gn_silu_backward(x_dev, da_dev, planes, g, bt, film_dev, silu, B, C, HW, ns, part, out_bc, dx_dev, dgamma_dev, dbeta_dev,
                             dfilm_dev, s);
     HIPCHECK(h, hipGetLastError());
-    HIPCHECK(h, hipStreamSynchronize(s));
-    for (void* p : {(void*)rec, (void*)g, (void*)bt, (void*)planes, (void*)out_bc, (void*)part}) (void)hipFree(p);
     return 0;
 }
 
@@ -1658,7 +1757,7 @@ int cddpm_stat_records(int H, int W, int kind) {
 }
 
 size_t cddpm_packed_conv_bytes(int Cout, int Cin, int taps) {
-    if (Cout <= 0 || Cin <= 0 || Cout % 128 || Cin % 32 || (taps != 1 && taps != 9)) return 0;
+    if (Cout <= 0 || Cin <= 0 || Cout % 128 || Cin % 32 || (taps != 1 && taps != 9 && taps != 4)) return 0;
     return packed_conv_floats(Cout, Cin, taps) * sizeof(float);
 }
 

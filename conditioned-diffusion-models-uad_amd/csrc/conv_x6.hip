@@ -34,6 +34,7 @@
 // A lane's 16-B fragment = 8 consecutive channels = its K elements of one k-step (lane>>5 selects the half).
 #include "kernels.h"
 #include "conv_split.h"
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -906,6 +907,71 @@ void pack_conv_weights_split(const float* w, int Cout, int Cin, int taps, void* 
                             }
                         }
             }
+}
+
+// ---- device twin of pack_conv_weights_split for the fp16 two-term family: the training step re-packs the updated weights each step
+// (same image, bit for bit, as the host packer for the same exponent). Element (o, i, t) of the packed tensor [O][I][taps]:
+//   mode 0 (forward)          w[(o I + i) taps + t]                      w = [O][I][k][k]
+//   mode 1 (input gradient)   w[(i O + o) taps + taps - 1 - t]           w = [I][O][k][k]: transposed and flipped
+//   mode 2 (folded upsample)  the class sums of pack_conv_weights_up2 (summed in double, rounded once); w = [O][I][3][3], taps = 4,
+//                             blockIdx.y = class
+__global__ __launch_bounds__(256) void pack_split_kernel(const float* __restrict__ w, int O, int I, int taps, int mode, int wexp,
+                                                         uint16_t* __restrict__ dst) {
+    const int ncb = O / 128, nch = I / 32;
+    const long long id = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (id >= (long long)ncb * nch * taps * 512) return;
+    const int u = (int)(id & 3), j = (int)((id >> 2) & 127);
+    long long rest = id >> 9;
+    const int t = (int)(rest % taps); rest /= taps;
+    const int ch = (int)(rest % nch);
+    const int cb = (int)(rest / nch);
+    const int cls = blockIdx.y;
+    uint16_t* img = dst + ((((size_t)cls * ncb + cb) * nch + ch) * taps + t) * (size_t)(128 * 8 * 8);
+    const int o = cb * 128 + j;
+    union { uint16_t q[8]; uint4 v; } hi, mid;
+    for (int e = 0; e < 8; ++e) {
+        const int i = ch * 32 + 8 * u + e;
+        float r;
+        if (mode == 0) r = w[((size_t)o * I + i) * taps + t];
+        else if (mode == 1) r = w[((size_t)i * O + o) * taps + (taps - 1 - t)];
+        else {
+            const int pa = cls >> 1, pb = cls & 1, ty = t >> 1, tx = t & 1;
+            const int ky0 = pa == 0 ? (ty == 0 ? 0 : 1) : (ty == 0 ? 0 : 2), ky1 = pa == 0 ? (ty == 0 ? 0 : 2) : (ty == 0 ? 1 : 2);
+            const int kx0 = pb == 0 ? (tx == 0 ? 0 : 1) : (tx == 0 ? 0 : 2), kx1 = pb == 0 ? (tx == 0 ? 0 : 2) : (tx == 0 ? 1 : 2);
+            double acc = 0.0;
+            for (int ky = ky0; ky <= ky1; ++ky)
+                for (int kx = kx0; kx <= kx1; ++kx) acc += (double)w[((size_t)o * I + i) * 9 + ky * 3 + kx];
+            r = (float)acc;
+        }
+        r = ldexpf(r, wexp);
+        const _Float16 h = (_Float16)r;
+        r -= (float)h;
+        const _Float16 m = (_Float16)r;
+        hi.q[e] = __builtin_bit_cast(uint16_t, h);
+        mid.q[e] = __builtin_bit_cast(uint16_t, m);
+    }
+    const int sw = (j >> 1) & 7;
+    *reinterpret_cast<uint4*>(img + (size_t)(j * 8 + ((0 + u) ^ sw)) * 8) = hi.v;
+    *reinterpret_cast<uint4*>(img + (size_t)(j * 8 + ((4 + u) ^ sw)) * 8) = mid.v;
+}
+void launch_pack_conv_split(const float* w, int O, int I, int taps, int mode, int wexp, void* dst, hipStream_t stream) {
+    const long long n = (long long)(O / 128) * (I / 32) * taps * 512;
+    hipLaunchKernelGGL(pack_split_kernel, dim3((unsigned)((n + 255) / 256), mode == 2 ? 4 : 1), dim3(256), 0, stream, w, O, I, taps, mode, wexp,
+                       static_cast<uint16_t*>(dst));
+}
+
+// max |x| over n floats into out[0] (out zeroed by the caller's memset; |x| compared as its bit pattern)
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, long long n, unsigned* __restrict__ out) {
+    unsigned m = 0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+        m = max(m, __float_as_uint(x[i]) & 0x7fffffffu);
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
+void launch_absmax(const float* x, long long n, float* out, hipStream_t stream) {
+    (void)hipMemsetAsync(out, 0, sizeof(float), stream);
+    const unsigned g = (unsigned)std::min<long long>((n + 255) / 256, 1024);
+    hipLaunchKernelGGL(absmax_kernel, dim3(g), dim3(256), 0, stream, x, n, reinterpret_cast<unsigned*>(out));
 }
 
 }  // namespace cddpm

@@ -67,6 +67,10 @@ void pack_conv_weights_split(const float* w /*[Cout][Cin][k][k]*/, int Cout, int
 // split layouts (conv_x6.hip): [..][128 rows x 4 NS slots of 8 x 16 bit]: 1.5 (bf16 x 3) | 1 (fp16 x 2) floats per weight
 size_t packed_conv_floats(int Cout, int Cin, int taps);
 // wexp: conv_weight_exp() of the tensor (and of every tensor accumulated into the same output tile); ignored unless mode 2
+// device packer of the fp16 two-term family (mode 0 forward, 1 transposed + flipped for the input gradient, 2 folded upsample classes) and
+// max |x| (the power-of-two pre-scale is chosen from it on the host)
+void launch_pack_conv_split(const float* w_dev, int O, int I, int taps, int mode, int wexp, void* dst_dev, hipStream_t stream);
+void launch_absmax(const float* x, long long n, float* out, hipStream_t stream);
 void pack_conv_weights(const float* w /*[Cout][Cin][k][k]*/, int Cout, int Cin, int taps, float* dst, int wexp);
 // folded weights of nearest-x2-upsample + 3x3: 4 parity classes x 4 taps = 4 * packed_conv_floats(Cout, Cin, 4) floats
 // returns the pre-scale exponent it chose for the folded weights (0 unless mode 2)

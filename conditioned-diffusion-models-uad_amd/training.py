@@ -29,19 +29,41 @@ def _p(t: Optional[torch.Tensor]):
 
 
 class UNetTrainer:
-    """Forward + backward of the conditioned UNet on NHWC device tensors. `params`: reference state_dict names -> fp32 CUDA tensors
-    (the master weights, updated in place by `adam_step`)."""
+    """Forward + backward + Adam of the conditioned UNet on NHWC device tensors, device-resident: the parameters live in ONE flat fp32
+    buffer (`flat`; `p[name]` are views with the reference's state_dict names and shapes), their gradients in a second one (`gflat`,
+    `g[name]`): every backward operator writes its parameter gradients straight into those views, the data-parallel all-reduce is one
+    collective over `gflat` and Adam one launch over `flat`. The convolution weights are re-packed on the device after every update
+    (cddpm_op_pack_conv) into the images the fused convolution kernel reads: a forward image and a transposed / flipped image for the
+    input gradient. No operator synchronises: temporaries come from the handle's scratch arena."""
 
     def __init__(self, params: Dict[str, torch.Tensor], *, model_channels=128, channel_mult=(1, 2, 2), num_res_blocks=3,
-                 cond_dim=128, engine: Optional[CddpmEngine] = None, device=None):
+                 cond_dim=128, device=None, exp_refresh=50):
         self.dev = torch.device(device) if device is not None else next(iter(params.values())).device
-        self.eng = engine
         self._cfg = dict(model_channels=model_channels, channel_mult=tuple(channel_mult), num_res_blocks=num_res_blocks, cond_dim=cond_dim)
-        self._fit(1, 16, 16)
         self.C, self.mult, self.nres, self.cond_dim = model_channels, tuple(channel_mult), num_res_blocks, cond_dim
-        self.p = {k: v.detach().to(self.dev, torch.float32).contiguous() for k, v in params.items()}
+        names = list(params)
+        sizes = [(int(params[k].numel()) + 63) // 64 * 64 for k in names]       # 256-byte aligned views
+        self.flat = torch.zeros(sum(sizes), dtype=torch.float32, device=self.dev)
+        self.gflat = torch.zeros_like(self.flat)
+        self.p: Dict[str, torch.Tensor] = {}
+        self.g: Dict[str, torch.Tensor] = {}
+        off = 0
+        for k, n in zip(names, sizes):
+            v = params[k]
+            self.p[k] = self.flat[off:off + v.numel()].view(v.shape)
+            self.g[k] = self.gflat[off:off + v.numel()].view(v.shape)
+            self.p[k].copy_(v.detach().to(self.dev, torch.float32))
+            off += n
         self.program = self._build_program()
-        self.state: Dict[str, torch.Tensor] = {}
+        self.state: Dict[str, object] = {}
+        self.eng: Optional[CddpmEngine] = None
+        self.grad_scale = 1.0
+        self.exp_refresh = exp_refresh
+        self._convs = self._conv_table()
+        self._fit(1, 16, 16)
+        if self._convs:
+            self.refresh_exponents()
+            self.repack()
 
     # ------------------------------------------------------------------ program (mirrors UNetModel.__init__, OpenAI_Unet.py:604-797)
     def _build_program(self):
@@ -76,15 +98,71 @@ class UNetTrainer:
         prog.append(("head", "out", dict(c=ch)))
         return prog
 
+    def _conv_table(self):
+        """every convolution that runs on the fused kernel: name -> (Cout, Cin, k, folded, exponent group). A ResBlock's second convolution
+        and its 1x1 skip_connection run as ONE launch and share the pre-scale exponent."""
+        t = {}
+        if "input_blocks.0.0.weight" not in self.p:
+            return t
+        for kind, name, a in self.program:
+            if kind == "res":
+                t[name + ".in_layers.2"] = (a["cout"], a["cin"], 3, a["kind"] == "up", name + ".in_layers.2")
+                t[name + ".out_layers.3"] = (a["cout"], a["cout"], 3, False, name + ".out_layers.3")
+                if a["cin"] != a["cout"]:
+                    t[name + ".skip_connection"] = (a["cout"], a["cin"], 1, False, name + ".out_layers.3")
+            elif kind == "attn":
+                t[name + ".qkv"] = (3 * a["c"], a["c"], 1, False, name + ".qkv")
+                t[name + ".proj_out"] = (a["c"], a["c"], 1, False, name + ".proj_out")
+        return t
+
+    # ------------------------------------------------------------------ handle, packed weights
     def _fit(self, B, H, W):
-        """the handle whose scratch (statistics records, split buffers) the operators use: grown when a larger batch arrives"""
+        """the handle the operators run on; its scratch arena is sized for the batch (attention backward keeps two B x heads x N x N
+        planes, the weight-gradient kernel its partial tiles)"""
         e = self.eng
         if e is None or e.max_batch < B or e.max_h < H or e.max_w < W:
-            if e is not None and getattr(self, "_own", False):
+            if e is not None:
+                torch.cuda.synchronize(self.dev)
                 e.close()
             self.eng = CddpmEngine(timesteps=2, max_batch=B, max_h=H, max_w=W, device=self.dev, **self._cfg)
-            self._own = True
+            nmid = (H >> (len(self.mult) - 1)) * (W >> (len(self.mult) - 1))
+            cmid = self.mult[-1] * self.C
+            arena = 2 * B * (cmid // 64) * nmid * nmid * 4 + (192 << 20)
+            rc = self.eng.lib.cddpm_op_set_scratch(self.eng._h, arena)
+            if rc != 0:
+                raise RuntimeError("cddpm_op_set_scratch failed: " + self.eng.lib.cddpm_last_error(self.eng._h).decode())
         self.lib, self.h = self.eng.lib, self.eng._h
+
+    def refresh_exponents(self):
+        """power-of-two pre-scale of each convolution weight for the fp16 operand split: the largest e in [0, 24] with max|w| 2^(e+1) < 2^14
+        (one bit of headroom: the weights move between refreshes; folded upsample classes sum up to four taps: two more bits)"""
+        names = list(self._convs)
+        mx = torch.zeros(len(names), dtype=torch.float32, device=self.dev)
+        for i, k in enumerate(names):
+            w = self.p[k + ".weight"]
+            self._ck(self.lib.cddpm_op_absmax(self.h, _p(w), w.numel(), mx[i:].data_ptr(), self._s()), "op_absmax")
+        mx = mx.cpu().tolist()                                   # the one host read-back, every `exp_refresh` steps
+        raw = {}
+        for k, m in zip(names, mx):
+            bound = m * (8.0 if self._convs[k][3] else 2.0)
+            e = 24
+            while e > 0 and math.ldexp(bound, e) >= 16384.0:
+                e -= 1
+            raw[k] = e
+        self.wexp = {k: min(raw[j] for j in names if self._convs[j][4] == self._convs[k][4]) for k in names}
+
+    def repack(self):
+        """device images of every convolution weight for the forward operator and for the input-gradient operator"""
+        if not hasattr(self, "pk"):
+            self.pk, self.pkT = {}, {}
+            for k, (co, ci, ks, folded, _g) in self._convs.items():
+                nb = 4 * self.lib.cddpm_packed_conv_bytes(co, ci, 4) if folded else self.lib.cddpm_packed_conv_bytes(co, ci, ks * ks)
+                self.pk[k] = torch.empty(nb, dtype=torch.uint8, device=self.dev)
+                self.pkT[k] = torch.empty(self.lib.cddpm_packed_conv_bytes(ci, co, ks * ks), dtype=torch.uint8, device=self.dev)
+        for k, (co, ci, ks, folded, _g) in self._convs.items():
+            w = self.p[k + ".weight"]
+            self._ck(self.lib.cddpm_op_pack_conv(self.h, _p(w), co, ci, ks, 2 if folded else 0, self.wexp[k], _p(self.pk[k]), self._s()), "op_pack_conv")
+            self._ck(self.lib.cddpm_op_pack_conv(self.h, _p(w), co, ci, ks, 1, self.wexp[k], _p(self.pkT[k]), self._s()), "op_pack_conv")
 
     # ------------------------------------------------------------------ thin operator wrappers (device pointers in, tensors out)
     def _ck(self, rc, what):
@@ -94,44 +172,89 @@ class UNetTrainer:
     def _s(self):
         return _stream_ptr(self.dev)
 
-    def linear(self, x, w, b, silu_in=False):
+    def _new(self, *shape):
+        return torch.empty(shape, dtype=torch.float32, device=self.dev)
+
+    def linear(self, x, name, silu_in=False):
+        w, b = self.p[name + ".weight"], self.p[name + ".bias"]
         M, K = x.shape
-        y = torch.empty((M, w.shape[0]), dtype=torch.float32, device=self.dev)
+        y = self._new(M, w.shape[0])
         self._ck(self.lib.cddpm_op_linear(self.h, _p(x), _p(w), _p(b), M, w.shape[0], K, int(silu_in), _p(y), self._s()), "op_linear")
         return y
 
-    def linear_bwd(self, x, w, dy, silu_in=False, need_dx=True):
-        dw, db, dx = self.eng.op_linear_backward(x, w, dy, silu_in=silu_in)
-        return dw, db, (dx if need_dx else None)
+    def linear_bwd(self, x, name, dy, silu_in=False, need_dx=True):
+        """writes dW, db of Linear `name` into the gradient buffer, returns dx"""
+        w = self.p[name + ".weight"]
+        M, K = x.shape
+        dx = self._new(M, K) if need_dx else self._new(M, K)
+        self._ck(self.lib.cddpm_op_linear_backward(self.h, _p(x), _p(w), _p(dy), M, w.shape[0], K, int(bool(silu_in)), _p(self.g[name + ".weight"]),
+                                                   _p(self.g[name + ".bias"]), _p(dx), self._s()), "op_linear_backward")
+        return dx
 
     def gn_coef(self, x0, x1, name, film=None):
-        return self.eng.op_gn_coef(x0, x1, self.p[name + ".weight"], self.p[name + ".bias"], film)
+        B, HW, C0 = x0.shape[0], x0.shape[1] * x0.shape[2], x0.shape[-1]
+        C1 = x1.shape[-1] if x1 is not None else 0
+        coef = self._new(3, B, C0 + C1)
+        self._ck(self.lib.cddpm_op_gn_coef(self.h, _p(x0), C0, _p(x1), C1, _p(self.p[name + ".weight"]), _p(self.p[name + ".bias"]), _p(film),
+                                           _p(coef), B, HW, self._s()), "op_gn_coef")
+        return coef
 
-    def conv(self, x0, x1, coef, silu, up, wname, bias, res, res_up, k):
-        return self.eng.op_conv(x0, x1, coef, silu, up, self.p[wname], bias, res, res_up, k)
+    def gn_bwd(self, x, da, name, film=None, silu=True):
+        """backward of act(GroupNorm32(x) (1 + scale) + shift): dgamma / dbeta go to the gradient buffer; -> (dx, dfilm or None)"""
+        B, H, W, Cc = x.shape
+        dx = torch.empty_like(x)
+        dfilm = self._new(B, 2 * Cc) if film is not None else None
+        self._ck(self.lib.cddpm_op_gn_silu_backward(self.h, _p(x), _p(da), _p(self.p[name + ".weight"]), _p(self.p[name + ".bias"]), _p(film),
+                                                    int(bool(silu)), _p(dx), _p(self.g[name + ".weight"]), _p(self.g[name + ".bias"]), _p(dfilm),
+                                                    B, H * W, Cc, self._s()), "op_gn_silu_backward")
+        return dx, dfilm
+
+    def conv(self, name, x0, x1=None, coef=None, silu=False, res=None, res_up=False, skip=None, skip_name=None, bias=None):
+        """fused forward convolution `name` on its packed image: conv_k(act(cat[x0, x1])) [+ conv1x1(skip)] + bias [+ res]"""
+        co, ci, ks, folded, _g = self._convs[name]
+        B, h_, w_, C0 = x0.shape
+        H, W = (2 * h_, 2 * w_) if folded else (h_, w_)
+        out = self._new(B, H, W, co)
+        b = bias if bias is not None else self.p[name + ".bias"]
+        self._ck(self.lib.cddpm_op_conv_packed(
+            self.h, _p(x0), C0, _p(x1), x1.shape[-1] if x1 is not None else 0, _p(coef), int(bool(silu)), int(folded), _p(self.pk[name]), self.wexp[name],
+            _p(b), co, ks, _p(res), int(bool(res_up)), _p(skip), skip.shape[-1] if skip is not None else 0,
+            _p(self.pk[skip_name]) if skip_name else None, _p(out), B, H, W, self._s()), "op_conv_packed")
+        return out
+
+    def dgrad(self, name, dy):
+        """dL/d(input) of convolution `name`: the same kernel on the transposed / flipped image"""
+        co, ci, ks, _folded, _g = self._convs[name]
+        B, H, W, _c = dy.shape
+        dx = self._new(B, H, W, ci)
+        self._ck(self.lib.cddpm_op_conv_packed(self.h, _p(dy), co, None, 0, None, 0, 0, _p(self.pkT[name]), self.wexp[name], None, ci, ks, None, 0,
+                                               None, 0, None, _p(dx), B, H, W, self._s()), "op_conv_packed (input gradient)")
+        return dx
+
+    def wgrad(self, name, x0, x1, coef, silu, dy, upsample=False, bias=True):
+        """dL/dW (and dL/db) of convolution `name` into the gradient buffer"""
+        co, ci, ks, _folded, _g = self._convs[name]
+        B, H, W, _c = dy.shape
+        self._ck(self.lib.cddpm_op_conv_wgrad(self.h, _p(x0), x0.shape[-1], _p(x1), x1.shape[-1] if x1 is not None else 0, _p(coef), int(bool(silu)),
+                                              int(bool(upsample)), _p(dy), co, ks, _p(self.g[name + ".weight"]),
+                                              _p(self.g[name + ".bias"]) if bias else None, B, H, W, self._s()), "op_conv_wgrad")
 
     def unpool2(self, dyp, scale, into=None):
         B, h, w, Cc = dyp.shape
-        out = into if into is not None else torch.empty((B, 2 * h, 2 * w, Cc), dtype=torch.float32, device=self.dev)
+        out = into if into is not None else self._new(B, 2 * h, 2 * w, Cc)
         self._ck(self.lib.cddpm_op_unpool2(self.h, _p(dyp), _p(out), B, 2 * h, 2 * w, Cc, C.c_float(scale), int(into is not None), self._s()),
                  "op_unpool2")
         return out
 
     def sumpool2(self, dy, into=None):
         B, H, W, Cc = dy.shape
-        out = into if into is not None else torch.empty((B, H // 2, W // 2, Cc), dtype=torch.float32, device=self.dev)
+        out = into if into is not None else self._new(B, H // 2, W // 2, Cc)
         self._ck(self.lib.cddpm_op_sumpool2(self.h, _p(dy), _p(out), B, H, W, Cc, int(into is not None), self._s()), "op_sumpool2")
         return out
 
     def add_(self, a, b):
         self._ck(self.lib.cddpm_op_add_inplace(self.h, _p(a), _p(b), a.numel(), self._s()), "op_add_inplace")
         return a
-
-    def bias_grad(self, dy):
-        Cc = dy.shape[-1]
-        db = torch.empty((Cc,), dtype=torch.float32, device=self.dev)
-        self._ck(self.lib.cddpm_op_bias_grad(self.h, _p(dy), dy.numel() // Cc, Cc, _p(db), self._s()), "op_bias_grad")
-        return db
 
     # ------------------------------------------------------------------ forward (OpenAI_Unet.py:823-1006), activations saved
     def forward(self, x: torch.Tensor, t: torch.Tensor, cond: torch.Tensor) -> torch.Tensor:
@@ -145,50 +268,50 @@ class UNetTrainer:
         freqs = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float32) / half)
         args = t.detach().cpu().float()[:, None] * freqs[None]
         temb = torch.cat([torch.cos(args), torch.sin(args)], dim=-1).to(self.dev)
-        y1 = self.linear(temb, p["time_embed.0.weight"], p["time_embed.0.bias"])
-        et = self.linear(y1, p["time_embed.2.weight"], p["time_embed.2.bias"], silu_in=True)
-        l1 = self.linear(cond.float().contiguous(), p["label_emb.0.weight"], p["label_emb.0.bias"])
-        ec = self.linear(l1, p["label_emb.2.weight"], p["label_emb.2.bias"], silu_in=True)
+        y1 = self.linear(temb, "time_embed.0")
+        et = self.linear(y1, "time_embed.2", silu_in=True)
+        cond = cond.float().contiguous()
+        l1 = self.linear(cond, "label_emb.0")
+        ec = self.linear(l1, "label_emb.2", silu_in=True)
         emb = torch.cat([et, ec], dim=1).contiguous()
-        sv.update(temb=temb, y1=y1, l1=l1, cond=cond.float().contiguous(), emb=emb, x=x)
+        sv.update(temb=temb, y1=y1, l1=l1, cond=cond, emb=emb, x=x)
         hs: List[torch.Tensor] = []
         cur = None
         for kind, name, a in self.program:
             if kind == "in":
-                cur = torch.empty((B, H, W, self.C), dtype=torch.float32, device=self.dev)
-                wv = p[name + ".weight"].reshape(self.C, 9).contiguous()
-                self._ck(self.lib.cddpm_op_conv_in1(self.h, _p(x), _p(wv), _p(p[name + ".bias"]), _p(cur), B, H, W, self.C, self._s()), "op_conv_in1")
+                cur = self._new(B, H, W, self.C)
+                self._ck(self.lib.cddpm_op_conv_in1(self.h, _p(x), _p(p[name + ".weight"]), _p(p[name + ".bias"]), _p(cur), B, H, W, self.C, self._s()),
+                         "op_conv_in1")
                 hs.append(cur)
             elif kind == "res":
                 x1 = hs.pop() if a.get("concat") else None
-                film = self.linear(emb, p[name + ".emb_layers.1.weight"], p[name + ".emb_layers.1.bias"], silu_in=True)
+                film = self.linear(emb, name + ".emb_layers.1", silu_in=True)
                 r = dict(x0=cur, x1=x1, film=film)
                 coef1 = self.gn_coef(cur, x1, name + ".in_layers.0")
                 r["coef1"] = coef1
+                c1, c2 = name + ".in_layers.2", name + ".out_layers.3"
                 if a["kind"] == "down":
                     Bc, h_, w_, Cc = cur.shape
-                    hp = torch.empty((Bc, h_ // 2, w_ // 2, Cc), dtype=torch.float32, device=self.dev)
-                    xp = torch.empty_like(hp)
+                    hp, xp = self._new(Bc, h_ // 2, w_ // 2, Cc), self._new(Bc, h_ // 2, w_ // 2, Cc)
                     self._ck(self.lib.cddpm_op_pool_act(self.h, _p(cur), _p(coef1), _p(hp), _p(xp), Bc, h_, w_, Cc, self._s()), "op_pool_act")
-                    h1 = self.conv(hp, None, None, False, 0, name + ".in_layers.2.weight", p[name + ".in_layers.2.bias"], None, False, 3)
+                    h1 = self.conv(c1, hp)
                     r.update(hp=hp)
                     resid, res_up = xp, False
                 elif a["kind"] == "up":
-                    h1 = self.conv(cur, None, coef1, True, 2, name + ".in_layers.2.weight", p[name + ".in_layers.2.bias"], None, False, 3)
+                    h1 = self.conv(c1, cur, None, coef1, True)
                     resid, res_up = cur, True
                 else:
-                    h1 = self.conv(cur, x1, coef1, True, 0, name + ".in_layers.2.weight", p[name + ".in_layers.2.bias"], None, False, 3)
+                    h1 = self.conv(c1, cur, x1, coef1, True)
                     resid, res_up = cur, False
                 coef2 = self.gn_coef(h1, None, name + ".out_layers.0", film)
                 r.update(h1=h1, coef2=coef2)
                 if a["cin"] != a["cout"]:
-                    xin = cur if x1 is None else torch.cat([cur, x1], dim=-1).contiguous()
+                    xin = cur if x1 is None else torch.cat([cur, x1], dim=-1)
                     r["xin"] = xin
-                    out = self.eng.op_conv_skip(h1, coef2, True, p[name + ".out_layers.3.weight"],
-                                                p[name + ".out_layers.3.bias"] + p[name + ".skip_connection.bias"], xin,
-                                                p[name + ".skip_connection.weight"])
+                    out = self.conv(c2, h1, None, coef2, True, skip=xin, skip_name=name + ".skip_connection",
+                                    bias=p[c2 + ".bias"] + p[name + ".skip_connection.bias"])
                 else:
-                    out = self.conv(h1, None, coef2, True, 0, name + ".out_layers.3.weight", p[name + ".out_layers.3.bias"], resid, res_up, 3)
+                    out = self.conv(c2, h1, None, coef2, True, res=resid, res_up=res_up)
                 sv[name] = r
                 cur = out
                 if a.get("push"):
@@ -196,15 +319,16 @@ class UNetTrainer:
             elif kind == "attn":
                 Bc, h_, w_, Cc = cur.shape
                 coefn = self.gn_coef(cur, None, name + ".norm")
-                qkv = self.conv(cur, None, coefn, False, 0, name + ".qkv.weight", p[name + ".qkv.bias"], None, False, 1)
-                att = self.eng.op_attention(qkv.reshape(Bc, h_ * w_, 3 * Cc))
-                out = self.conv(att.reshape(Bc, h_, w_, Cc), None, None, False, 0, name + ".proj_out.weight", p[name + ".proj_out.bias"], cur, False, 1)
+                qkv = self.conv(name + ".qkv", cur, None, coefn, False)
+                att = self._new(Bc, h_, w_, Cc)
+                self._ck(self.lib.cddpm_op_attention(self.h, _p(qkv), _p(att), Bc, h_ * w_, Cc, self._s()), "op_attention")
+                out = self.conv(name + ".proj_out", att, res=cur)
                 sv[name] = dict(x=cur, coefn=coefn, qkv=qkv, att=att)
                 cur = out
             else:   # head: GroupNorm -> SiLU -> Conv2d(C -> 1)
                 coefo = self.gn_coef(cur, None, "out.0")
                 w9 = p["out.2.weight"].reshape(a["c"], 9).t().contiguous()
-                out = torch.empty((B, 1, H, W), dtype=torch.float32, device=self.dev)
+                out = self._new(B, 1, H, W)
                 self._ck(self.lib.cddpm_op_head(self.h, _p(cur), _p(coefo), _p(w9), C.c_float(float(p["out.2.bias"][0])), _p(out), B, H, W, a["c"],
                                                 self._s()), "op_head")
                 sv["out"] = dict(x=cur, coefo=coefo, w9=w9)
@@ -214,7 +338,8 @@ class UNetTrainer:
 
     # ------------------------------------------------------------------ backward: dL/d(model output) -> gradients of every parameter
     def backward(self, dout: torch.Tensor) -> Dict[str, torch.Tensor]:
-        p, sv, g = self.p, self.saved, {}
+        """fills `g` (views of `gflat`) from dout = grad_scale * dL/d(model output); returns `g`"""
+        p, sv, g = self.p, self.saved, self.g
         B, _c, H, W = dout.shape
         dout = dout.contiguous().float()
         demb = torch.zeros_like(sv["emb"])
@@ -223,73 +348,56 @@ class UNetTrainer:
         for kind, name, a in reversed(self.program):
             if kind == "head":
                 r, Cc = sv["out"], a["c"]
-                dact = torch.empty((B, H, W, Cc), dtype=torch.float32, device=self.dev)
+                dact = self._new(B, H, W, Cc)
                 self._ck(self.lib.cddpm_op_head_dgrad(self.h, _p(dout), _p(r["w9"]), _p(dact), B, H, W, Cc, self._s()), "op_head_dgrad")
-                dw = torch.empty((Cc, 9), dtype=torch.float32, device=self.dev)
-                self._ck(self.lib.cddpm_op_chan_image_corr(self.h, _p(r["x"]), _p(r["coefo"]), 1, _p(dout), -1, _p(dw), B, H, W, Cc, self._s()),
-                         "op_chan_image_corr")
-                g["out.2.weight"] = dw.reshape(1, Cc, 3, 3)
-                g["out.2.bias"] = dout.sum().reshape(1)
-                d, g["out.0.weight"], g["out.0.bias"], _ = self.eng.op_gn_silu_backward(r["x"], dact, p["out.0.weight"], p["out.0.bias"], None, True)
+                self._ck(self.lib.cddpm_op_chan_image_corr(self.h, _p(r["x"]), _p(r["coefo"]), 1, _p(dout), -1, _p(g["out.2.weight"]), B, H, W, Cc,
+                                                           self._s()), "op_chan_image_corr")
+                g["out.2.bias"].copy_(dout.sum().reshape(1))          # one scalar
+                d, _ = self.gn_bwd(r["x"], dact, "out.0")
             elif kind == "attn":
                 r = sv[name]
+                da = self.dgrad(name + ".proj_out", d)
+                self.wgrad(name + ".proj_out", r["att"], None, None, False, d)
                 Bc, h_, w_, Cc = r["x"].shape
-                da = self.eng.op_conv_dgrad(d, p[name + ".proj_out.weight"])
-                g[name + ".proj_out.weight"], g[name + ".proj_out.bias"] = self.eng.op_conv_wgrad(r["att"].reshape(Bc, h_, w_, Cc), None, None, False, d, ksize=1)
-                dqkv = self.eng.op_attention_backward(r["qkv"].reshape(Bc, h_ * w_, 3 * Cc), da.reshape(Bc, h_ * w_, Cc)).reshape(Bc, h_, w_, 3 * Cc)
-                dn = self.eng.op_conv_dgrad(dqkv, p[name + ".qkv.weight"])
-                g[name + ".qkv.weight"], g[name + ".qkv.bias"] = self.eng.op_conv_wgrad(r["x"], None, r["coefn"], False, dqkv, ksize=1)
-                dx, g[name + ".norm.weight"], g[name + ".norm.bias"], _ = self.eng.op_gn_silu_backward(r["x"], dn, p[name + ".norm.weight"],
-                                                                                                     p[name + ".norm.bias"], None, False)
+                dqkv = torch.empty_like(r["qkv"])
+                self._ck(self.lib.cddpm_op_attention_backward(self.h, _p(r["qkv"]), _p(da), _p(dqkv), Bc, h_ * w_, Cc, self._s()),
+                         "op_attention_backward")
+                dn = self.dgrad(name + ".qkv", dqkv)
+                self.wgrad(name + ".qkv", r["x"], None, r["coefn"], False, dqkv)
+                dx, _ = self.gn_bwd(r["x"], dn, name + ".norm", None, False)
                 d = self.add_(dx, d)
             elif kind == "res":
                 if a.get("push"):        # this op's output also fed a skip connection: add that gradient
                     d = self.add_(d, skip_grads.pop())
                 r = sv[name]
                 x0, x1, h1, film = r["x0"], r["x1"], r["h1"], r["film"]
-                w1, w2 = p[name + ".in_layers.2.weight"], p[name + ".out_layers.3.weight"]
+                c1, c2 = name + ".in_layers.2", name + ".out_layers.3"
                 # out = conv2(act2(h1)) + skip(x)
-                da2 = self.eng.op_conv_dgrad(d, w2)
-                g[name + ".out_layers.3.weight"], g[name + ".out_layers.3.bias"] = self.eng.op_conv_wgrad(h1, None, r["coef2"], True, d, ksize=3)
+                da2 = self.dgrad(c2, d)
+                self.wgrad(c2, h1, None, r["coef2"], True, d)
+                dxs = None
                 if a["cin"] != a["cout"]:
-                    ws = p[name + ".skip_connection.weight"]
-                    dxs = self.eng.op_conv_dgrad(d, ws)                       # [B,H,W,Cin] over the concatenation
-                    c0 = x0.shape[-1]
-                    g[name + ".skip_connection.weight"], g[name + ".skip_connection.bias"] = self.eng.op_conv_wgrad(x0, x1, None, False, d, ksize=1)
-                else:
-                    dxs = None
-                dh1, g[name + ".out_layers.0.weight"], g[name + ".out_layers.0.bias"], dfilm = self.eng.op_gn_silu_backward(
-                    h1, da2, p[name + ".out_layers.0.weight"], p[name + ".out_layers.0.bias"], film, True)
-                # film = Linear(SiLU(emb))
-                g[name + ".emb_layers.1.weight"], g[name + ".emb_layers.1.bias"], de = self.linear_bwd(sv["emb"], p[name + ".emb_layers.1.weight"], dfilm, True)
-                self.add_(demb, de)
-                # h1 = conv1(...)
-                xin = x0 if x1 is None else r.get("xin", None)
-                if x1 is not None and xin is None:
-                    xin = torch.cat([x0, x1], dim=-1).contiguous()
+                    dxs = self.dgrad(name + ".skip_connection", d)            # [B,H,W,Cin] over the concatenation
+                    self.wgrad(name + ".skip_connection", x0, x1, None, False, d)
+                dh1, dfilm = self.gn_bwd(h1, da2, name + ".out_layers.0", film)
+                self.add_(demb, self.linear_bwd(sv["emb"], name + ".emb_layers.1", dfilm, True))       # film = Linear(SiLU(emb))
                 if a["kind"] == "down":
-                    dhp = self.eng.op_conv_dgrad(dh1, w1)
-                    g[name + ".in_layers.2.weight"], g[name + ".in_layers.2.bias"] = self.eng.op_conv_wgrad(r["hp"], None, None, False, dh1, ksize=3)
+                    dhp = self.dgrad(c1, dh1)
+                    self.wgrad(c1, r["hp"], None, None, False, dh1)
                     da1 = self.unpool2(dhp, 0.25)
-                    dx, g[name + ".in_layers.0.weight"], g[name + ".in_layers.0.bias"], _ = self.eng.op_gn_silu_backward(
-                        x0, da1, p[name + ".in_layers.0.weight"], p[name + ".in_layers.0.bias"], None, True)
+                    dx, _ = self.gn_bwd(x0, da1, name + ".in_layers.0")
                     self.unpool2(d, 0.25, into=dx)                            # identity skip through avg_pool(x)
                 elif a["kind"] == "up":
-                    dau = self.eng.op_conv_dgrad(dh1, w1)                      # gradient of the upsampled activation
-                    g[name + ".in_layers.2.weight"], g[name + ".in_layers.2.bias"] = self.eng.op_conv_wgrad(x0, None, r["coef1"], True, dh1, ksize=3, upsample=True)
+                    dau = self.dgrad(c1, dh1)                                 # gradient of the upsampled activation
+                    self.wgrad(c1, x0, None, r["coef1"], True, dh1, upsample=True)
                     da1 = self.sumpool2(dau)
-                    dx, g[name + ".in_layers.0.weight"], g[name + ".in_layers.0.bias"], _ = self.eng.op_gn_silu_backward(
-                        x0, da1, p[name + ".in_layers.0.weight"], p[name + ".in_layers.0.bias"], None, True)
+                    dx, _ = self.gn_bwd(x0, da1, name + ".in_layers.0")
                     self.sumpool2(d, into=dx)                                 # identity skip through the upsampled x
                 else:
-                    da1 = self.eng.op_conv_dgrad(dh1, w1)
-                    g[name + ".in_layers.2.weight"], g[name + ".in_layers.2.bias"] = self.eng.op_conv_wgrad(x0, x1, r["coef1"], True, dh1, ksize=3)
-                    dx, g[name + ".in_layers.0.weight"], g[name + ".in_layers.0.bias"], _ = self.eng.op_gn_silu_backward(
-                        xin, da1, p[name + ".in_layers.0.weight"], p[name + ".in_layers.0.bias"], None, True)
-                    if dxs is not None:
-                        self.add_(dx, dxs)
-                    else:
-                        self.add_(dx, d)                                      # identity skip
+                    da1 = self.dgrad(c1, dh1)
+                    self.wgrad(c1, x0, x1, r["coef1"], True, dh1)
+                    dx, _ = self.gn_bwd(r["xin"] if x1 is not None else x0, da1, name + ".in_layers.0")
+                    self.add_(dx, dxs if dxs is not None else d)              # 1x1 skip_connection, or the identity skip
                 if x1 is not None:       # split the gradient of the concatenation: [h | popped skip tensor]
                     c0 = x0.shape[-1]
                     skip_grads.append(dx[..., c0:].contiguous())
@@ -298,20 +406,18 @@ class UNetTrainer:
                     d = dx
             else:   # input conv
                 d = self.add_(d, skip_grads.pop())
-                dw = torch.empty((self.C, 9), dtype=torch.float32, device=self.dev)
-                self._ck(self.lib.cddpm_op_chan_image_corr(self.h, _p(d), None, 0, _p(sv["x"]), 1, _p(dw), B, H, W, self.C, self._s()),
+                self._ck(self.lib.cddpm_op_chan_image_corr(self.h, _p(d), None, 0, _p(sv["x"]), 1, _p(g[name + ".weight"]), B, H, W, self.C, self._s()),
                          "op_chan_image_corr")
-                g[name + ".weight"] = dw.reshape(self.C, 1, 3, 3)
-                g[name + ".bias"] = self.bias_grad(d)
+                self._ck(self.lib.cddpm_op_bias_grad(self.h, _p(d), B * H * W, self.C, _p(g[name + ".bias"]), self._s()), "op_bias_grad")
         assert not skip_grads
         # embedding MLPs (OpenAI_Unet.py:598-602, :583-590)
         hw = sv["emb"].shape[1] // 2
         det, dec = demb[:, :hw].contiguous(), demb[:, hw:].contiguous()
-        g["time_embed.2.weight"], g["time_embed.2.bias"], dy1 = self.linear_bwd(sv["y1"], p["time_embed.2.weight"], det, True)
-        g["time_embed.0.weight"], g["time_embed.0.bias"], _ = self.linear_bwd(sv["temb"], p["time_embed.0.weight"], dy1, False, need_dx=False)
-        g["label_emb.2.weight"], g["label_emb.2.bias"], dl1 = self.linear_bwd(sv["l1"], p["label_emb.2.weight"], dec, True)
-        g["label_emb.0.weight"], g["label_emb.0.bias"], dcond = self.linear_bwd(sv["cond"], p["label_emb.0.weight"], dl1, False)
-        self.dcond = dcond           # gradient w.r.t. the context vector (what the encoder's backward would consume)
+        dy1 = self.linear_bwd(sv["y1"], "time_embed.2", det, True)
+        self.linear_bwd(sv["temb"], "time_embed.0", dy1, False)
+        dl1 = self.linear_bwd(sv["l1"], "label_emb.2", dec, True)
+        self.dcond = self.linear_bwd(sv["cond"], "label_emb.0", dl1, False)      # gradient w.r.t. the context vector (the encoder's input gradient)
+        self.saved = None
         return g
 
     # ------------------------------------------------------------------ loss of p_losses + one optimizer step
@@ -319,25 +425,37 @@ class UNetTrainer:
         """-> (loss, grad_scale * dL/d(model_out)); grad_scale defaults to B*H*W rounded up to a power of two (see cddpm_op_loss)"""
         B, _c, H, W = model_out.shape
         dout = torch.empty_like(model_out)
-        loss_b = torch.empty((B,), dtype=torch.float32, device=self.dev)
+        loss_b = self._new(B)
         self.grad_scale = float(grad_scale) if grad_scale is not None else float(2 ** math.ceil(math.log2(B * H * W)))
         self._ck(self.lib.cddpm_op_loss(self.h, _p(model_out), _p(target.contiguous().float()), _p(p2w), int(loss_type == "l2"), B, H * W,
                                         C.c_float(self.grad_scale), _p(dout), _p(loss_b), self._s()), "op_loss")
         return loss_b.mean(), dout
 
-    def adam_step(self, grads: Dict[str, torch.Tensor], lr=1e-4, betas=(0.9, 0.999), eps=1e-8, grad_scale=None):
-        """torch.optim.Adam(lr=1e-4) of DDPM_2D.configure_optimizers (DDPM_2D.py:305-306) on every UNet parameter"""
+    def adam_step(self, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, grad_scale=None):
+        """torch.optim.Adam(lr=1e-4) of DDPM_2D.configure_optimizers (DDPM_2D.py:305-306) on every parameter: one launch over the flat buffers
+        (gradient = gflat / grad_scale), then the convolution images are re-packed from the updated weights"""
         st = self.state
-        unscale = 1.0 / (grad_scale if grad_scale is not None else getattr(self, "grad_scale", 1.0))
-        st["step"] = st.get("step", 0) + 1
-        for k, gr in grads.items():
-            w = self.p[k]
-            if k not in st:
-                st[k] = (torch.zeros_like(w), torch.zeros_like(w))
-            m, v = st[k]
-            gr = gr.reshape(w.shape).contiguous()
-            self._ck(self.lib.cddpm_op_adam(self.h, _p(w), _p(gr), _p(m), _p(v), w.numel(), C.c_float(lr), C.c_float(betas[0]), C.c_float(betas[1]),
-                                            C.c_float(eps), st["step"], C.c_float(unscale), self._s()), "op_adam")
+        if "m" not in st:
+            st["m"], st["v"], st["step"] = torch.zeros_like(self.flat), torch.zeros_like(self.flat), 0
+        st["step"] += 1
+        unscale = 1.0 / (grad_scale if grad_scale is not None else self.grad_scale)
+        self._ck(self.lib.cddpm_op_adam(self.h, _p(self.flat), _p(self.gflat), _p(st["m"]), _p(st["v"]), self.flat.numel(), C.c_float(lr),
+                                        C.c_float(betas[0]), C.c_float(betas[1]), C.c_float(eps), st["step"], C.c_float(unscale), self._s()), "op_adam")
+        if self._convs:
+            if self.exp_refresh and st["step"] % self.exp_refresh == 0:
+                self.refresh_exponents()
+            self.repack()
+
+
+def all_reduce_sum_(flat: torch.Tensor) -> int:
+    """the data-parallel gradient exchange (the reference trains under Lightning DDP, src/train.py:62-65): ONE all-reduce over the flat
+    gradient buffer (43.9 M floats = 176 MB: a single large ring collective, what xGMI's per-link bandwidth wants). Returns the number of
+    ranks summed over; the caller divides (training_step folds it into Adam's unscale factor)."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(flat)
+        return dist.get_world_size()
+    return 1
 
 
 def training_step(trainer: UNetTrainer, x01: torch.Tensor, cond: torch.Tensor, *, t: torch.Tensor, noise: torch.Tensor, timesteps=1000,
@@ -355,16 +473,7 @@ def training_step(trainer: UNetTrainer, x01: torch.Tensor, cond: torch.Tensor, *
     target = noise if objective == "pred_noise" else x0
     p2w = buf["p2_loss_weight"].to(dev)[t].contiguous()
     loss, dout = trainer.loss_and_grad(out, target, p2w, loss_type)
-    grads = trainer.backward(dout)
-    if all_reduce:
-        import torch.distributed as dist
-        flat = torch.cat([grads[k].reshape(-1) for k in sorted(grads)])
-        dist.all_reduce(flat)
-        flat /= dist.get_world_size()
-        off = 0
-        for k in sorted(grads):
-            n = grads[k].numel()
-            grads[k] = flat[off:off + n].reshape(grads[k].shape)
-            off += n
-    trainer.adam_step(grads, lr=lr)
+    trainer.backward(dout)
+    world = all_reduce_sum_(trainer.gflat) if all_reduce else 1
+    trainer.adam_step(lr=lr, grad_scale=trainer.grad_scale * world)        # the mean over ranks folds into Adam's unscale factor
     return loss

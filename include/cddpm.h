@@ -238,7 +238,8 @@ int cddpm_op_gn_coef(cddpm_handle h, const float* src0_dev, int C0, const float*
  * format = 0: conv_mfma.hip (CDDPM_CONV=f32) -- fp32, [..][128 rows][8 slots of 4 floats], slot s of row j at
  *   s ^ ((j >> 1) & 7); 4 bytes per weight.
  * cddpm_packed_conv_bytes returns the image size; cddpm_pack_conv_weights fills dst_host (that many bytes) from
- * PyTorch-layout w_host [Cout][Cin][k][k] (taps = k*k in {1, 9}) and returns the format, or -1 on a bad shape. */
+ * PyTorch-layout w_host [Cout][Cin][k][k] (taps = k*k in {1, 9}; the size query also takes 4, one folded-upsample class) and returns
+ * the format, or -1 on a bad shape. */
 size_t cddpm_packed_conv_bytes(int Cout, int Cin, int taps);
 int cddpm_pack_conv_weights(const float* w_host, int Cout, int Cin, int taps, void* dst_host, int* scale_exp_out);
 
@@ -301,6 +302,27 @@ int cddpm_op_loss(cddpm_handle h, const float* out_dev, const float* target_dev,
  * g_dev * grad_unscale (1 / the loss scale) */
 int cddpm_op_adam(cddpm_handle h, float* p_dev, const float* g_dev, float* m_dev, float* v_dev, int64_t n, float lr, float beta1, float beta2,
                   float eps, int step, float grad_unscale, void* stream);
+/* ---- device-resident operator calls (what the training step runs on: no host staging, no synchronisation) ----
+ * cddpm_op_set_scratch gives the handle an arena of `bytes` (0: release it) from which the operators of this header take their
+ * temporaries instead of a hipMalloc / synchronise / hipFree per call; calls then only enqueue work on `stream` (one stream).
+ * An operator that needs more than the arena holds fails with the size in cddpm_last_error.
+ * Parameter vectors documented as *_host (GroupNorm gamma / beta) may be device pointers: they are then used where they lie.
+ * cddpm_op_absmax: out_dev[0] = max |x| (the caller derives a tensor's power-of-two pre-scale from it: the largest e in [0, 24] with
+ * max|w| 2^e < 2^14). cddpm_op_pack_conv: the packed image of cddpm_pack_conv_weights (format 2), written by a kernel from the device
+ * tensor w_dev [Cout][Cin][k][k]; mode 0 = forward operator, 1 = the input-gradient operator (transposed, taps flipped: Cin outputs,
+ * Cout inputs; cddpm_packed_conv_bytes(Cin, Cout, k*k) bytes), 2 = the four folded classes of "nearest x2 upsample -> conv3x3"
+ * (4 * cddpm_packed_conv_bytes(Cout, Cin, 4) bytes; the class sums can reach 4 max|w|). Bit-identical to the host packer for the same
+ * exponent. Default convolution family only.
+ * cddpm_op_conv_packed: cddpm_op_conv / cddpm_op_conv_skip on such images: out = conv_k(act(cat[src0, src1])) [+ conv1x1(skip)] + bias
+ * [+ res]; bias_dev NULL = none; skip_dev NULL = no skip segment (its image shares scale_exp); folded_up: src0 is at H/2 x W/2. */
+int cddpm_op_set_scratch(cddpm_handle h, size_t bytes);
+int cddpm_op_absmax(cddpm_handle h, const float* x_dev, int64_t n, float* out_dev, void* stream);
+int cddpm_op_pack_conv(cddpm_handle h, const float* w_dev, int Cout, int Cin, int ksize, int mode, int scale_exp, void* packed_dev,
+                       void* stream);
+int cddpm_op_conv_packed(cddpm_handle h, const float* src0_dev, int C0, const float* src1_dev, int C1, const float* coef_dev, int silu,
+                         int folded_up, const void* packed_dev, int scale_exp, const float* bias_dev, int Cout, int ksize,
+                         const float* res_dev, int res_upsample, const float* skip_dev, int S0, const void* skip_packed_dev,
+                         float* out_dev, int B, int H, int W, void* stream);
 /* backward of a = act(GroupNorm32(x) * (1 + scale) + shift), act = SiLU (silu != 0) or identity (OpenAI_Unet.py:284-338, :325-330):
  * given da_dev [B,HW,C] writes dx_dev [B,HW,C], dgamma_dev / dbeta_dev [C] and, when film_dev ([B][2C] scale | shift) is given,
  * dfilm_dev [B][2C]. The forward statistics are recomputed from x_dev. Everything NHWC fp32. */

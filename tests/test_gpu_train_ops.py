@@ -129,3 +129,27 @@ def test_linear_backward_vs_autograd(eng, M, N, K, silu):
     r = [float((g.cpu().double() - t).abs().max() / t.abs().max()) for g, t in ((dw, w.grad), (db, b.grad), (dx, x.grad))]
     print(M, N, K, silu, [f"{v:.2e}" for v in r])
     assert max(r) < 1e-5
+
+
+@pytest.mark.parametrize("Cout,Cin,k", [(128, 128, 3), (256, 384, 3), (768, 256, 1), (128, 384, 1)])
+def test_device_weight_packer_is_the_host_packer(eng, Cout, Cin, k):
+    """cddpm_op_pack_conv (the training step re-packs the updated weights on the device every step) writes, bit for bit, the image of the
+    host packer cddpm_pack_conv_weights for the same exponent: forward image, and the transposed / flipped image of the input gradient"""
+    import ctypes as C
+    torch.manual_seed(Cout + Cin + k)
+    w = (torch.randn(Cout, Cin, k, k) * 0.05).contiguous()
+    lib, taps = eng.lib, k * k
+    for mode in (0, 1):
+        O, I = (Cout, Cin) if mode == 0 else (Cin, Cout)
+        src = w if mode == 0 else w.transpose(0, 1).flip(2, 3).contiguous()
+        nb = lib.cddpm_packed_conv_bytes(O, I, taps)
+        host = np.zeros(nb, dtype=np.uint8)
+        e = C.c_int(-1)
+        fmt = lib.cddpm_pack_conv_weights(src.numpy().ctypes.data_as(C.POINTER(C.c_float)), O, I, taps, host.ctypes.data, C.byref(e))
+        assert fmt == 2 and 0 <= e.value <= 24
+        dev = torch.zeros(nb, dtype=torch.uint8, device="cuda")
+        wd = w.cuda()
+        rc = lib.cddpm_op_pack_conv(eng._h, wd.data_ptr(), Cout, Cin, k, mode, e.value, dev.data_ptr(), None)
+        assert rc == 0, lib.cddpm_last_error(eng._h)
+        torch.cuda.synchronize()
+        assert np.array_equal(dev.cpu().numpy(), host), (mode, int((dev.cpu().numpy() != host).sum()))

@@ -92,7 +92,8 @@ def test_adam_update_vs_torch():
         gr = torch.randn(4099) * (10.0 ** (step - 1))
         ref.grad = gr.double()
         opt.step()
-        trainer.adam_step({"w": gr.to(dev)}, lr=1e-4)
+        trainer.g["w"].copy_(gr.to(dev))
+        trainer.adam_step(lr=1e-4, grad_scale=1.0)
     got = trainer.p["w"].double().cpu()
     assert float((got - ref.detach()).abs().max()) < 1e-6      # fp32 master weights of magnitude ~1 against a float64 optimizer
 
