@@ -1586,9 +1586,12 @@ int cddpm_op_conv_dgrad(cddpm_handle h, const float* dy_dev, int Cout, const flo
 
 int cddpm_op_bias_grad(cddpm_handle h, const float* dy_dev, int64_t npix, int C, float* db_dev, void* stream) {
     if (!h) return -1;
-    if (!dy_dev || !db_dev || npix < 1 || C % 4) return fail(h, "cddpm_op_bias_grad: bad arguments");
+    if (!dy_dev || !db_dev || npix < 1 || C % 4 || C > 1024) return fail(h, "cddpm_op_bias_grad: bad arguments");
     HIPCHECK(h, hipSetDevice(h->device));
-    launch_bias_grad(dy_dev, npix, C, db_dev, (hipStream_t)stream);
+    OpScratch sc(h, (hipStream_t)stream);
+    double* part = sc.n<double>((size_t)256 * C);
+    SCRATCH_CHECK(sc)
+    launch_bias_grad(dy_dev, npix, C, db_dev, part, (hipStream_t)stream);
     HIPCHECK(h, hipGetLastError());
     return 0;
 }

@@ -159,7 +159,7 @@ void launch_gn_bwd_planes(const float* rec, int nrec, const float* gamma, const 
 int conv_wgrad_parts(int B, int H, int W, int Cin, int Cout, int taps);
 void launch_conv_wgrad(const float* x0, int C0, const float* x1, int C1, const float* coef, int silu, int up, const float* dy, int B, int H,
                        int W, int Cout, int taps, float* part, int P, float* dw, float* db, hipStream_t stream);
-void launch_bias_grad(const float* dy, long long npix, int C, float* db, hipStream_t stream);
+void launch_bias_grad(const float* dy, long long npix, int C, float* db, double* scratch /* 256 * C doubles */, hipStream_t stream);
 // QKVAttention backward: qkv [B][N][3C] (q | k | v), da [B][N][C] -> dqkv [B][N][3C]; p, dp: scratch [B * C / 64][N][N] floats each
 void launch_attention_backward(const float* qkv, const float* da, float* dqkv, float* p, float* dp, int B, int N, int C,
                                hipStream_t stream);

@@ -361,22 +361,42 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float* __r
     dw[e] = s;
 }
 
-__global__ __launch_bounds__(256) void bias_grad_kernel(const float* __restrict__ dy, long long npix, int Cout, float* __restrict__ db) {
-    // one workgroup per 4-channel quad: fp64 inside, rounded once
-    __shared__ double red[256][5];
-    const int cq = blockIdx.x, tid = threadIdx.x;
+// dL/db = sum over pixels of dy: pixel chunks across workgroups (coalesced float4 rows, fp64 partial sums), then one fold
+__global__ __launch_bounds__(256) void bias_grad_partial_kernel(const float* __restrict__ dy, long long npix, int C, int nchunk,
+                                                                double* __restrict__ part) {
+    __shared__ double red[1024];
+    const int nq = C >> 2, rows = 256 / nq, tid = threadIdx.x, q = tid % nq, r = tid / nq;
+    const long long per = (npix + nchunk - 1) / nchunk, p0 = per * blockIdx.x, p1 = p0 + per < npix ? p0 + per : npix;
     double s[4] = {0, 0, 0, 0};
-    for (long long p = tid; p < npix; p += 256) {
-        const float4 v = *reinterpret_cast<const float4*>(dy + (size_t)p * Cout + 4 * cq);
-        s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
+    if (r < rows)
+        for (long long p = p0 + r; p < p1; p += rows) {
+            const float4 v = *reinterpret_cast<const float4*>(dy + (size_t)p * C + 4 * q);
+            s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
+        }
+    for (int rr = 0; rr < rows; ++rr) {          // fold the rows one at a time through a C-wide buffer
+        __syncthreads();
+        if (r == rr) for (int i = 0; i < 4; ++i) red[4 * q + i] = (rr ? red[4 * q + i] : 0.0) + s[i];
     }
-    for (int i = 0; i < 4; ++i) red[tid][i] = s[i];
     __syncthreads();
-    if (tid < 4) {
-        double t = 0;
-        for (int l = 0; l < 256; ++l) t += red[l][tid];
-        db[4 * cq + tid] = (float)t;
-    }
+    for (int c = tid; c < C; c += 256) part[(size_t)blockIdx.x * C + c] = red[c];
+}
+__global__ __launch_bounds__(256) void bias_grad_fold_kernel(const double* __restrict__ part, int nchunk, int C, float* __restrict__ db) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    double t = 0;
+    for (int k = 0; k < nchunk; ++k) t += part[(size_t)k * C + c];
+    db[c] = (float)t;
+}
+// scratch: nchunk * C doubles, nchunk = bias_grad_chunks(npix, C, scratch floats available)
+int bias_grad_chunks(long long npix, int C, size_t scratch_floats) {
+    long long n = (long long)(scratch_floats / 2 / (size_t)C);
+    if (n > 256) n = 256;
+    if (n > npix) n = npix;
+    return n < 1 ? 1 : (int)n;
+}
+static void bias_grad_run(const float* dy, long long npix, int C, float* db, double* scratch, int nchunk, hipStream_t stream) {
+    hipLaunchKernelGGL(bias_grad_partial_kernel, dim3(nchunk), dim3(256), 0, stream, dy, npix, C, nchunk, scratch);
+    hipLaunchKernelGGL(bias_grad_fold_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, scratch, nchunk, C, db);
 }
 
 int conv_wgrad_parts(int B, int H, int W, int Cin, int Cout, int taps) {
@@ -400,7 +420,10 @@ void launch_conv_wgrad(const float* x0, int C0, const float* x1, int C1, const f
     else           hipLaunchKernelGGL(conv_wgrad_kernel<1>, dim3(grid), dim3(256), 0, stream, a);
     const long long n = (long long)Cout * Cin * taps;
     hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, part, P, Cout, Cin, taps, dw);
-    if (db) hipLaunchKernelGGL(bias_grad_kernel, dim3(Cout / 4), dim3(256), 0, stream, dy, (long long)B * H * W, Cout, db);
+    if (db) {   // the partial tiles are folded by now (stream order): their memory serves as the bias sum's scratch
+        const size_t part_floats = (size_t)P * Cout * Cin * taps;
+        bias_grad_run(dy, (long long)B * H * W, Cout, db, reinterpret_cast<double*>(part), bias_grad_chunks((long long)B * H * W, Cout, part_floats), stream);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -764,8 +787,8 @@ __global__ __launch_bounds__(256) void loss_kernel(const float* __restrict__ out
     for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
     if (tid == 0) loss_b[b] = (float)(red[0] / HW * wb);
 }
-void launch_bias_grad(const float* dy, long long npix, int C, float* db, hipStream_t stream) {
-    hipLaunchKernelGGL(bias_grad_kernel, dim3(C / 4), dim3(256), 0, stream, dy, npix, C, db);
+void launch_bias_grad(const float* dy, long long npix, int C, float* db, double* scratch /* 256 * C doubles */, hipStream_t stream) {
+    bias_grad_run(dy, npix, C, db, scratch, bias_grad_chunks(npix, C, (size_t)512 * C), stream);
 }
 void launch_loss(const float* out, const float* target, const float* w_b, int l2, int B, int HW, float grad_scale, float* dout, float* loss_b,
                  hipStream_t stream) {

@@ -79,3 +79,35 @@ def test_shard_range_partition():
             rs = [sh.shard_range(n, r, w) for r in range(w)]
             assert rs[0][0] == 0 and rs[-1][1] == n and all(rs[i][1] == rs[i + 1][0] for i in range(w - 1))
             assert max(b - a for a, b in rs) - min(b - a for a, b in rs) <= 1
+
+
+def _grad_worker(rank, world, port, q):
+    import importlib
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    tr = importlib.import_module(PKG_NAME + ".training")
+    flat = torch.arange(1000, dtype=torch.float32) * (rank + 1)          # rank r holds (r + 1) * g
+    n = tr.all_reduce_sum_(flat)
+    q.put((rank, n, flat.numpy().copy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradient_all_reduce():
+    """the training step's data-parallel exchange (training.all_reduce_sum_): one collective over the flat gradient buffer; the mean is
+    the sum divided by the returned rank count (folded into Adam's unscale factor by training_step)"""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_grad_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    expect = (torch.arange(1000, dtype=torch.float32) * 3).numpy()
+    for _rank, n, flat in got:
+        assert n == 2 and (flat == expect).all()

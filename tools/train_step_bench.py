@@ -1,0 +1,68 @@
+"""Times the training step (training.py: forward + loss + backward + Adam, all on the HIP operators) on one GPU.
+    python tools/train_step_bench.py [--batch 16] [--size 128] [--steps 5] [--warmup 2]
+BASELINE config 5 is 128x1x128x128 over 8 GPUs data-parallel = 16 slices per GPU and step."""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+PKG = "conditioned-diffusion-models-uad_amd"
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--size", type=int, default=128)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--phases", action="store_true", help="time forward / backward / adam separately (synchronises between them)")
+    a = ap.parse_args()
+    tr = importlib.import_module(PKG + ".training")
+    synth = importlib.import_module(PKG + ".synth")
+    dev = torch.device("cuda", 0)
+    sd = synth.synth_state_dict(0)
+    trainer = tr.UNetTrainer({k: torch.from_numpy(v) for k, v in sd.items()}, device=dev)
+    B, S, T = a.batch, a.size, 1000
+    x01 = torch.from_numpy(synth.synth_slices(1, 0, B, S, S)).reshape(B, 1, S, S).to(dev)
+    cond = torch.from_numpy(synth.synth_cond(1, 0, B)).to(dev)
+    noise = torch.from_numpy(synth.noise_xT(1, 0, B, S, S)).reshape(B, 1, S, S).to(dev)
+    t = torch.tensor([(137 * (i + 1)) % T for i in range(B)], dtype=torch.long, device=dev)
+    losses = []
+    for _ in range(a.warmup):
+        losses.append(float(tr.training_step(trainer, x01, cond, t=t, noise=noise, objective="pred_noise", loss_type="l2")))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = tr.training_step(trainer, x01, cond, t=t, noise=noise, objective="pred_noise", loss_type="l2")
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / a.steps
+    losses.append(float(loss))
+    res = {"workload": f"training step {B}x1x{S}x{S} (noise-pred MSE, fp32-emulated convolutions, Adam)", "ms_per_step": dt * 1e3,
+           "slices_per_s": B / dt, "losses": losses, "peak_mem_GB": torch.cuda.max_memory_allocated() / 2 ** 30}
+    if a.phases:
+        buf = importlib.import_module(PKG + ".schedule").schedule_buffers(T)
+        x0 = x01 * 2 - 1
+        xt = (buf["sqrt_alphas_cumprod"].to(dev)[t].reshape(-1, 1, 1, 1) * x0 + buf["sqrt_one_minus_alphas_cumprod"].to(dev)[t].reshape(-1, 1, 1, 1) * noise)
+        ph = {}
+        for _ in range(2):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            out = trainer.forward(xt, t, cond)
+            torch.cuda.synchronize(); t1 = time.perf_counter()
+            _l, dout = trainer.loss_and_grad(out, noise, None, "l2")
+            trainer.backward(dout)
+            torch.cuda.synchronize(); t2 = time.perf_counter()
+            trainer.adam_step()
+            torch.cuda.synchronize(); t3 = time.perf_counter()
+            ph = {"forward_ms": (t1 - t0) * 1e3, "loss_backward_ms": (t2 - t1) * 1e3, "adam_repack_ms": (t3 - t2) * 1e3}
+        res["phases"] = ph
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()
