@@ -12,7 +12,8 @@ Added, behind a cfg switch that is absent (= reference behaviour) by default:
 `test_step` follows the reference's evaluation call (:171-286): 4 centre slices, `noise_ensemble` / `step_ensemble`
 averaging, a fresh `gen_noise` (device simplex) field per reconstruction.
 The context encoder is this package's native ResNet-50 (DDPM_encoder.py) unless an
-`encoder=` module is supplied. Out of scope here: training and the scipy post-processing of utils_eval (f4). pytorch_lightning / omegaconf are used when installed and replaced by
+`encoder=` module is supplied. `training_step` runs the UNet's optimisation step on the HIP operators (training.py; the encoder is
+not updated). The scipy post-processing of utils_eval lives in utils_eval.py. pytorch_lightning / omegaconf are used when installed and replaced by
 nn.Module / a plain attribute dict when not.
 """
 from __future__ import annotations
@@ -185,6 +186,61 @@ class DDPM_2D(_Base):
             if _test_step is not None:
                 _test_step(self, final_volume, data_orig, data_seg, data_mask, batch_idx, batch.get("ID"), batch.get("label"))
         return out
+
+    # ------------------------------------------------------------------ training (reference :114-135, :305-306)
+    def hip_trainer(self, device):
+        """the UNet's training state on the HIP operators (training.UNetTrainer). From here on the UNet module's parameters ARE views of
+        the trainer's flat buffer: state_dict() / checkpoints see the trained values, and the evaluation path re-packs them on its next call."""
+        if getattr(self, "_trainer", None) is None:
+            from .training import UNetTrainer
+            unet = self.diffusion.model
+            ds, levels = 1, len(unet.channel_mult)
+            for _lvl in range(levels):
+                if ds in tuple(unet.attention_resolutions):
+                    raise NotImplementedError("training: attention inside the resolution levels is not built (the cDDPM experiment has none: "
+                                              "att_res [3, 6, 12] never matches ds in {1, 2, 4})")
+                ds *= 2
+            self._trainer = UNetTrainer({k: v for k, v in unet.state_dict().items()}, model_channels=unet.model_channels,
+                                        channel_mult=tuple(unet.channel_mult), num_res_blocks=unet.num_res_blocks,
+                                        cond_dim=unet.num_classes, device=device)
+            for k, prm in unet.named_parameters():
+                prm.data = self._trainer.p[k]
+        return self._trainer
+
+    def training_step(self, batch, batch_idx: int):
+        """One optimisation step of the reference's training_step (:114-135): input = batch['vol'][DATA].squeeze(-1), context = encoder(input),
+        noise = gen_noise(cfg) or Gaussian, loss = diffusion(input, cond, noise) at random t (cond_DDPM.py:647-655) -- with the gradient,
+        the data-parallel all-reduce and Adam(lr = cfg.lr) (:305-306) done HERE on the HIP operators (training.training_step): this module
+        runs under Lightning's manual optimisation (`automatic_optimization = False`), there is no autograd graph to hand back.
+        Deviation, stated: the context encoder is not updated (its backward is not built; `hip_trainer(...).dcond` holds dL/d(context)
+        for whoever trains it); the reference with pretrained_encoder=False trains it jointly."""
+        from . import training as _training
+        vol = batch["vol"]
+        input = vol["data"].squeeze(-1).float()              # torchio's DATA key is the string "data"
+        dev = input.device
+        features = self(input)
+        noise = self._gen_noise(input.shape, dev)
+        if noise is None:
+            noise = torch.randn_like(input)
+        d = self.diffusion
+        t = torch.randint(0, d.num_timesteps, (input.shape[0],), device=dev).long()
+        trainer = self.hip_trainer(dev)
+        ddp = torch.distributed.is_available() and torch.distributed.is_initialized()
+        loss = _training.training_step(trainer, input, features.float(), t=t, noise=noise.float(), timesteps=d.num_timesteps,
+                                       objective=d.objective, loss_type=d.loss_type, all_reduce=ddp, lr=_cfg_get(self.cfg, "lr", 1e-4),
+                                       buffers={k: getattr(d, k) for k in ("sqrt_alphas_cumprod", "sqrt_one_minus_alphas_cumprod",
+                                                                           "p2_loss_weight")})
+        d.model._hip.invalidate()
+        if hasattr(self, "log") and _Base is not nn.Module:
+            try:
+                self.log(f"{self.prefix}train/Loss", loss, prog_bar=False, on_step=False, on_epoch=True, batch_size=input.shape[0], sync_dist=True)
+            except Exception:
+                pass
+        return {"loss": loss.detach()}
+
+    @property
+    def automatic_optimization(self):        # Lightning: training_step above steps the optimizer itself
+        return False
 
     def configure_optimizers(self):
         return torch.optim.Adam(self.parameters(), lr=_cfg_get(self.cfg, "lr", 1e-4))

@@ -64,6 +64,11 @@ class HipBackend:
             self._sched_key = skey
         return e
 
+    def invalidate(self):
+        """the parameters were updated outside torch's version counters (the training step's Adam kernel writes them in place): the next
+        `get` re-packs the inference engine's weights"""
+        self._key = None
+
     def close(self):
         if self.engine is not None:
             self.engine.close()

@@ -459,11 +459,12 @@ def all_reduce_sum_(flat: torch.Tensor) -> int:
 
 
 def training_step(trainer: UNetTrainer, x01: torch.Tensor, cond: torch.Tensor, *, t: torch.Tensor, noise: torch.Tensor, timesteps=1000,
-                  objective="pred_x0", loss_type="l1", all_reduce=False, lr=1e-4):
+                  objective="pred_x0", loss_type="l1", all_reduce=False, lr=1e-4, buffers=None):
     """One optimisation step of the diffusion loss (cond_DDPM.py:647-655 -> :565-645; DDPM_2D.py:114-135): x01 [B,1,H,W] in [0,1], context
-    cond [B,cond_dim], per-sample timesteps t and noise given by the caller. Returns the loss. `all_reduce`: average the gradients over
-    the ranks of torch.distributed (RCCL) before the update -- the data-parallel training of the reference (Lightning DDP)."""
-    buf = _schedule.schedule_buffers(timesteps)
+    cond [B,cond_dim], per-sample timesteps t and noise given by the caller; `buffers`: the diffusion's schedule tables (default: the
+    cosine schedule of `timesteps`). Returns the loss. `all_reduce`: sum the gradients over the ranks of torch.distributed (RCCL) before
+    the update -- the data-parallel training of the reference (Lightning DDP, src/train.py:62-65)."""
+    buf = buffers if buffers is not None else _schedule.schedule_buffers(timesteps)
     dev = trainer.dev
     x0 = x01.float() * 2 - 1
     sa = buf["sqrt_alphas_cumprod"].to(dev)[t].reshape(-1, 1, 1, 1)

@@ -178,3 +178,33 @@ def test_ddpm2d_test_step_noise_ensemble_vs_oracle_composition(sd_np, synth, ora
     print(f"test_step (noise ensemble, simplex) vs oracle composition: max|delta| {err:.3e}")
     assert err < TOL and float(ref.std()) > 0.01
     mod.diffusion.model._hip.close()
+
+
+def test_ddpm2d_training_step_updates_the_unet(sd_np, synth):
+    """the LightningModule mirror's training_step (reference src/models/DDPM_2D.py:114-135 + :305-306): a few steps on one batch run on the
+    HIP operators, lower the loss of a fixed probe, move the UNet's parameters (state_dict sees them) and the evaluation path picks the
+    updated weights up (the inference engine re-packs)"""
+    M = load_pkg("DDPM_2D")
+    cfg = dict(imageDim=[64, 64, 100], rescaleFactor=2, unet_dim=128, dim_mults=[1, 2, 2], condition=True, test_timesteps=500, timesteps=1000,
+               lr=1e-4)
+
+    class Enc(torch.nn.Module):          # stand-in for the context encoder (not updated by training_step)
+        def forward(self, x):
+            return x.flatten(1)[:, :128].contiguous() * 2 - 1
+
+    mod = M.DDPM_2D(cfg, encoder=Enc())
+    mod.diffusion.model.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()})
+    mod = mod.cuda()
+    vol = torch.from_numpy(synth.synth_slices(4, 0, 2, 32, 32)).reshape(2, 1, 32, 32, 1).cuda()       # what batch['vol'][DATA] holds for 2D slices
+    inp = vol.squeeze(-1)
+    probe_noise = torch.randn_like(inp)
+    loss0, reco0 = mod.reconstruct(inp, noise=probe_noise)
+    w_before = mod.diffusion.model.state_dict()["middle_block.0.in_layers.2.weight"].clone()
+    torch.manual_seed(0)
+    losses = [float(mod.training_step({"vol": {"data": vol}}, i)["loss"]) for i in range(6)]
+    assert all(np.isfinite(losses))
+    w_after = mod.diffusion.model.state_dict()["middle_block.0.in_layers.2.weight"]
+    assert float((w_after - w_before).abs().max()) > 1e-5                      # Adam moved the weights (lr 1e-4 per step)
+    loss1, reco1 = mod.reconstruct(inp, noise=probe_noise)
+    assert float((reco1 - reco0).abs().max()) > 1e-4                           # ... and evaluation runs on the updated weights
+    print("training losses", losses, "probe", float(loss0), "->", float(loss1))
