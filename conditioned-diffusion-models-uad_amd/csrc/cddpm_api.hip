@@ -1589,7 +1589,7 @@ int cddpm_op_bias_grad(cddpm_handle h, const float* dy_dev, int64_t npix, int C,
     if (!dy_dev || !db_dev || npix < 1 || C % 4 || C > 1024) return fail(h, "cddpm_op_bias_grad: bad arguments");
     HIPCHECK(h, hipSetDevice(h->device));
     OpScratch sc(h, (hipStream_t)stream);
-    double* part = sc.n<double>((size_t)256 * C);
+    double* part = sc.n<double>((size_t)512 * C);
     SCRATCH_CHECK(sc)
     launch_bias_grad(dy_dev, npix, C, db_dev, part, (hipStream_t)stream);
     HIPCHECK(h, hipGetLastError());
@@ -1600,9 +1600,10 @@ int cddpm_op_conv_wgrad(cddpm_handle h, const float* x0_dev, int C0, const float
                         int upsample, const float* dy_dev, int Cout, int ksize, float* dw_dev, float* db_dev, int B, int H, int W,
                         void* stream) {
     if (!h) return -1;
-    const int Cin = C0 + C1, taps = ksize * ksize, ck = (ksize == 3) ? 32 : 64;
-    if ((ksize != 1 && ksize != 3) || C0 <= 0 || C1 < 0 || Cin % ck || (C1 > 0 && C0 % 64) || Cout <= 0 || Cout % 64 || H < 4 || H % 4 ||
-        W < 1 || B < 1 || (C1 > 0 && !x1_dev) || (upsample && (C1 > 0 || (W & 1))))
+    const bool f32k = wgrad_mode() == 0;      // the fp32-MFMA family walks 4-row tiles and 64-channel chunks of a 1x1 kernel
+    const int Cin = C0 + C1, taps = ksize * ksize, ck = (ksize == 3 || !f32k) ? 32 : 64;
+    if ((ksize != 1 && ksize != 3) || C0 <= 0 || C1 < 0 || Cin % ck || (C1 > 0 && C0 % ck) || Cout <= 0 || Cout % 64 || H < 1 ||
+        (f32k && (H < 4 || H % 4)) || W < 1 || B < 1 || (C1 > 0 && !x1_dev) || (upsample && (C1 > 0 || (W & 1) || (H & 1))))
         return fail(h, "cddpm_op_conv_wgrad: unsupported shape (k %d, C0 %d, C1 %d, Cout %d, H %d)", ksize, C0, C1, Cout, H);
     if (!x0_dev || !dy_dev || !dw_dev) return fail(h, "cddpm_op_conv_wgrad: NULL argument");
     hipStream_t s = (hipStream_t)stream;
@@ -1610,8 +1611,10 @@ int cddpm_op_conv_wgrad(cddpm_handle h, const float* x0_dev, int C0, const float
     const int P = conv_wgrad_parts(B, H, W, Cin, Cout, taps);
     OpScratch sc(h, s);
     float* part = sc.n<float>((size_t)P * Cout * Cin * taps);
+    const size_t iu = conv_wgrad_image_units(B, H, W, Cin, Cout, taps);
+    void* images = iu ? sc.get(iu * 16) : nullptr;
     SCRATCH_CHECK(sc)
-    launch_conv_wgrad(x0_dev, C0, x1_dev, C1, coef_dev, silu, upsample ? 1 : 0, dy_dev, B, H, W, Cout, taps, part, P, dw_dev, db_dev, s);
+    launch_conv_wgrad(x0_dev, C0, x1_dev, C1, coef_dev, silu, upsample ? 1 : 0, dy_dev, B, H, W, Cout, taps, part, P, images, dw_dev, db_dev, s);
     HIPCHECK(h, hipGetLastError());
     return 0;
 }

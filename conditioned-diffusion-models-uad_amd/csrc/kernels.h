@@ -156,10 +156,12 @@ void launch_gn_bwd_planes(const float* rec, int nrec, const float* gamma, const 
                           float* planes, hipStream_t stream);
 // conv wgrad (3x3 pad 1, or 1x1): dw [Cout][Cin][k][k] (PyTorch layout), db [Cout] or nullptr; input = cat[x0 (C0), x1 (C1)];
 // part: scratch of conv_wgrad_parts() * Cout * Cin * taps floats. Cin multiple of 32 (3x3) / 64 (1x1), C0 of 64, Cout of 64, H of 4
+int wgrad_mode();      // CDDPM_WGRAD: 2 = h3 (default), 1 = h1, 0 = f32
 int conv_wgrad_parts(int B, int H, int W, int Cin, int Cout, int taps);
+size_t conv_wgrad_image_units(int B, int H, int W, int Cin, int Cout, int taps);   // 16-byte units of `images` (0: not used by this call)
 void launch_conv_wgrad(const float* x0, int C0, const float* x1, int C1, const float* coef, int silu, int up, const float* dy, int B, int H,
-                       int W, int Cout, int taps, float* part, int P, float* dw, float* db, hipStream_t stream);
-void launch_bias_grad(const float* dy, long long npix, int C, float* db, double* scratch /* 256 * C doubles */, hipStream_t stream);
+                       int W, int Cout, int taps, float* part, int P, void* images, float* dw, float* db, hipStream_t stream);
+void launch_bias_grad(const float* dy, long long npix, int C, float* db, double* scratch /* 512 * C doubles */, hipStream_t stream);
 // QKVAttention backward: qkv [B][N][3C] (q | k | v), da [B][N][C] -> dqkv [B][N][3C]; p, dp: scratch [B * C / 64][N][N] floats each
 void launch_attention_backward(const float* qkv, const float* da, float* dqkv, float* p, float* dp, int B, int N, int C,
                                hipStream_t stream);

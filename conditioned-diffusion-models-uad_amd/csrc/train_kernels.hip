@@ -19,6 +19,8 @@
 // Not here yet: attention backward, the one-channel input / output convolutions, the embedding MLPs, the
 // up/down-sampling variants, Adam, the gradient all-reduce, the step's orchestration.
 #include "kernels.h"
+#include <cstdlib>
+#include <cstring>
 
 namespace cddpm {
 
@@ -345,12 +347,373 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a) {
         }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// conv wgrad on the 16-bit matrix pipe (the default): the same contraction, products formed like the forward kernel's -- both operands
+// split into NS fp16 terms (NS = 2: hi . hi + hi . mid + mid . hi, fp32-grade; NS = 1: plain fp16 operands with fp32 accumulation,
+// the arithmetic of the reference trainer's `precision: 16`), v_mfma_f32_16x16x32_f16.
+//
+// That MFMA wants, per lane, 8 consecutive k of one row. The contraction index is (sample, y, x), the operands are NHWC, and a tap
+// shifts (y, x) by one -- an 8-vector along x or y would be misaligned for eight of the nine taps. So the 8-vector runs over the
+// BATCH: k = (pixel, sample mod 8). A staging thread owns one (pixel, channel quad), loads the 8 samples of a batch group (8 coalesced
+// float4 rows, one per sample), applies GroupNorm / FiLM / SiLU, splits, and writes for each of its 4 channels ONE 16-byte unit
+// [8 samples] to LDS at [channel][pixel]: no scattered 2-byte stores, no shuffles, and a tap is a plain (aligned) pixel offset.
+// Channel rows are padded by one unit so that the 16 channels a fragment read touches fall into distinct bank groups.
+// Workgroup = 4 waves on a 64 co x 32 ci (x 9 taps) tile, pixel tile 2 x 8 (+ halo), one batch group at a time: 80 KB of LDS, two
+// workgroups per CU -- one stages while the other multiplies. Wave = (co 32-block) x (taps 0..4 | 5..8) [3x3] or (ci 16-half) [1x1].
+// ------------------------------------------------------------------------------------------------------------------
+typedef _Float16 wg_f16x8 __attribute__((ext_vector_type(8)));
+typedef float wg_v4f __attribute__((ext_vector_type(4)));
+
+template <int TAPS, int NS>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_x_kernel(const WgradArgs a, int G) {
+    constexpr int PAD = (TAPS == 9) ? 1 : 0;
+    constexpr int TX = 8, TY = 2, NPX = TX * TY;
+    constexpr int PW = TX + 2 * PAD, PH = TY + 2 * PAD, NHP = PW * PH;          // 10 x 4 = 40 halo pixels | 16
+    constexpr int CK = 32;
+    constexpr int APITCH = NHP + 1, DPITCH = NPX + 1;                           // 16-byte units per channel row
+    constexpr int NT = (TAPS == 9) ? 5 : 1, NJ = (TAPS == 9) ? 2 : 1;          // taps and ci 16-blocks per wave
+    __shared__ uint4 actL[NS][CK * APITCH];
+    __shared__ uint4 dyL[NS][64 * DPITCH];
+    __shared__ float coefL[3][8][CK];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cw = wave & 1, tg = wave >> 1;
+    const int r = lane & 15, g = lane >> 4;
+    const int Cin = a.C0 + a.C1, nchunk = Cin / CK, ncb = a.Cout >> 6;
+    int bid = blockIdx.x;
+    const int chunk = bid % nchunk; bid /= nchunk;
+    const int cb = bid % ncb;
+    const int p = bid / ncb;
+    const int tilesX = (a.W + TX - 1) / TX, tilesY = (a.H + TY - 1) / TY, tpg = tilesX * tilesY;
+    const int ntile = G * tpg;
+    const int t0 = (int)((long long)ntile * p / a.P), t1 = (int)((long long)ntile * (p + 1) / a.P);
+    const int tapbase = (TAPS == 9) ? tg * 5 : 0, ntap = (TAPS == 9) ? (tg ? 4 : 5) : 1;
+    const int ch0 = chunk * CK;
+    const float* xsrc = (ch0 < a.C0) ? a.x0 : a.x1;
+    const int Cs = (ch0 < a.C0) ? a.C0 : a.C1, cs0 = (ch0 < a.C0) ? ch0 : ch0 - a.C0;
+    const int sH = a.up ? a.H >> 1 : a.H, sW = a.up ? a.W >> 1 : a.W;
+    wg_v4f acc[2][NJ][NT];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[i][j][t] = wg_v4f{0.f, 0.f, 0.f, 0.f};
+    int cur_grp = -1;
+    for (int tile = t0; tile < t1; ++tile) {
+        const int grp = tile / tpg, tt = tile - grp * tpg;
+        const int y0 = (tt / tilesX) * TY, x0 = (tt % tilesX) * TX;
+        __syncthreads();                          // the previous tile's fragments have been read
+        if (grp != cur_grp) {                     // (mean, a, d) of the group's 8 samples x 32 channels
+            for (int e = tid; e < 3 * 8 * CK; e += 256) {
+                const int pl = e / (8 * CK), i = (e / CK) & 7, c = e & (CK - 1), b = grp * 8 + i;
+                coefL[pl][i][c] = (a.coef && b < a.B) ? a.coef[((size_t)pl * a.B + b) * Cin + ch0 + c] : (pl == 1 ? 1.f : 0.f);
+            }
+            cur_grp = grp;
+            __syncthreads();
+        }
+        // dy tile: 16 pixels x 16 channel quads, one task per thread
+        {
+            const int n = tid >> 4, q = tid & 15;
+            const int y = y0 + (n >> 3), x = x0 + (n & 7);
+            const bool in = y < a.H && x < a.W;
+            float4 v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int b = grp * 8 + i;
+                v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (in && b < a.B) v[i] = *reinterpret_cast<const float4*>(a.dy + ((size_t)(b * a.H + y) * a.W + x) * a.Cout + cb * 64 + 4 * q);
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                wg_f16x8 h, m;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float f = c == 0 ? v[i].x : c == 1 ? v[i].y : c == 2 ? v[i].z : v[i].w;
+                    h[i] = (_Float16)f;
+                    m[i] = (_Float16)(f - (float)h[i]);
+                }
+                dyL[0][(4 * q + c) * DPITCH + n] = __builtin_bit_cast(uint4, h);
+                if (NS == 2) dyL[NS - 1][(4 * q + c) * DPITCH + n] = __builtin_bit_cast(uint4, m);
+            }
+        }
+        // activated patch: NHP pixels x 8 channel quads
+        for (int task = tid; task < NHP * 8; task += 256) {
+            const int hp = task >> 3, q = task & 7;
+            const int gy = y0 - PAD + hp / PW, gx = x0 - PAD + hp % PW;
+            const bool in = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+            const int sy = a.up ? gy >> 1 : gy, sx = a.up ? gx >> 1 : gx;
+            float4 v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int b = grp * 8 + i;
+                v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (in && b < a.B) v[i] = *reinterpret_cast<const float4*>(xsrc + ((size_t)(b * sH + sy) * sW + sx) * Cs + cs0 + 4 * q);
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                wg_f16x8 h, m;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    float f = c == 0 ? v[i].x : c == 1 ? v[i].y : c == 2 ? v[i].z : v[i].w;
+                    f = (f - coefL[0][i][4 * q + c]) * coefL[1][i][4 * q + c] + coefL[2][i][4 * q + c];
+                    if (a.silu) f = silu_t(f);
+                    if (!(in && grp * 8 + i < a.B)) f = 0.f;          // padding pixels and samples past the batch contribute nothing
+                    h[i] = (_Float16)f;
+                    m[i] = (_Float16)(f - (float)h[i]);
+                }
+                actL[0][(4 * q + c) * APITCH + hp] = __builtin_bit_cast(uint4, h);
+                if (NS == 2) actL[NS - 1][(4 * q + c) * APITCH + hp] = __builtin_bit_cast(uint4, m);
+            }
+        }
+        __syncthreads();
+        // 4 k-steps of 4 pixels x 8 samples; A = dy[co][k], B = act[k + tap][ci]
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int ty = ks >> 1, tx = 4 * (ks & 1) + g;
+            wg_f16x8 fa[NS][2];
+#pragma unroll
+            for (int s2 = 0; s2 < NS; ++s2)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) fa[s2][i] = __builtin_bit_cast(wg_f16x8, dyL[s2][(cw * 32 + i * 16 + r) * DPITCH + ty * TX + tx]);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                if (t < ntap) {
+                    const int tap = tapbase + t, ky = (TAPS == 9) ? tap / 3 : 0, kx = (TAPS == 9) ? tap - 3 * ky : 0;
+                    wg_f16x8 fb[NS][NJ];
+#pragma unroll
+                    for (int s2 = 0; s2 < NS; ++s2)
+#pragma unroll
+                        for (int j = 0; j < NJ; ++j) {
+                            const int ci = (TAPS == 9) ? j * 16 + r : tg * 16 + r;
+                            fb[s2][j] = __builtin_bit_cast(wg_f16x8, actL[s2][ci * APITCH + (ty + ky) * PW + tx + kx]);
+                        }
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < NJ; ++j) {
+                            if (NS == 2) {
+                                acc[i][j][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[NS - 1][i], fb[0][j], acc[i][j][t], 0, 0, 0);
+                                acc[i][j][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[0][i], fb[NS - 1][j], acc[i][j][t], 0, 0, 0);
+                            }
+                            acc[i][j][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[0][i], fb[0][j], acc[i][j][t], 0, 0, 0);
+                        }
+                }
+            }
+        }
+    }
+    // partial tile [64 co][TAPS][32 ci]; D row = co = 4 g + e, column = ci = r
+    float* o = a.part + ((((size_t)p * ncb + cb) * nchunk + chunk) * 64) * TAPS * CK;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+        if (t < ntap) {
+            const int tap = tapbase + t;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int co = cw * 32 + i * 16 + 4 * g + e, ci = (TAPS == 9) ? j * 16 + r : tg * 16 + r;
+                        o[((size_t)co * TAPS + tap) * CK + ci] = acc[i][j][t][e];
+                    }
+        }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// The 3x3 weight gradient in two passes (the default): (1) wgrad_image_kernel writes each operand ONCE as its "k-image" -- activated
+// (GroupNorm / FiLM / SiLU, upsampled where the convolution reads an upsampled input), split into NS fp16 planes, laid out
+// [plane][batch group][channel][y][x][8 samples] (16-byte units) -- so the transform and the SiLU are paid once per element instead of
+// once per (output-channel block x halo overlap) as in conv_wgrad_x_kernel above; (2) conv_wgrad_img_kernel is then a pure fp16 GEMM
+// over those images: staging is 16-byte copies (a 10-pixel halo row = 160 contiguous bytes), the next tile's units are fetched into
+// registers while the current tile's MFMAs run, and two workgroups share a CU. Same tile, wave roles, k order and partial layout as
+// conv_wgrad_x_kernel; the images cost one extra write + read of each operand (= its fp32 size per pass), ~1 % of the kernel's time.
+// ------------------------------------------------------------------------------------------------------------------
+struct ImageArgs {
+    const float* x0; const float* x1; int C0, C1;
+    const float* coef; int silu, up;
+    int B, H, W, G;
+    uint4* img;            // [NS][G][C0 + C1][H * W]
+    int NS;
+};
+
+__global__ __launch_bounds__(256) void wgrad_image_kernel(const ImageArgs a) {
+    // workgroup = 8 consecutive pixels x 32 channel quads; wave = 8 pixels x 8 quads: loads and stores are whole 128-byte lines
+    const int tid = threadIdx.x, px = tid & 7, q = blockIdx.y * 32 + (tid >> 3), grp = blockIdx.z;
+    const int C = a.C0 + a.C1, HW = a.H * a.W;
+    const int n = blockIdx.x * 8 + px;
+    if (n >= HW || 4 * q >= C) return;
+    const int y = n / a.W, x = n - y * a.W;
+    const int c0 = 4 * q;
+    const float* src = (c0 < a.C0) ? a.x0 : a.x1;
+    const int Cs = (c0 < a.C0) ? a.C0 : a.C1, cs = (c0 < a.C0) ? c0 : c0 - a.C0;
+    const int sH = a.up ? a.H >> 1 : a.H, sW = a.up ? a.W >> 1 : a.W, sy = a.up ? y >> 1 : y, sx = a.up ? x >> 1 : x;
+    float4 v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int b = grp * 8 + i;
+        v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (b < a.B) {
+            v[i] = *reinterpret_cast<const float4*>(src + ((size_t)(b * sH + sy) * sW + sx) * Cs + cs);
+            if (a.coef) {
+                const size_t pl = (size_t)a.B * C, bc = (size_t)b * C + c0;
+                const float4 m = *reinterpret_cast<const float4*>(a.coef + bc), gg = *reinterpret_cast<const float4*>(a.coef + pl + bc);
+                const float4 d = *reinterpret_cast<const float4*>(a.coef + 2 * pl + bc);
+                v[i].x = (v[i].x - m.x) * gg.x + d.x; v[i].y = (v[i].y - m.y) * gg.y + d.y;
+                v[i].z = (v[i].z - m.z) * gg.z + d.z; v[i].w = (v[i].w - m.w) * gg.w + d.w;
+            }
+            if (a.silu) { v[i].x = silu_t(v[i].x); v[i].y = silu_t(v[i].y); v[i].z = silu_t(v[i].z); v[i].w = silu_t(v[i].w); }
+        }
+    }
+    const size_t plane = (size_t)a.G * C * HW;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        wg_f16x8 h, m;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float f = c == 0 ? v[i].x : c == 1 ? v[i].y : c == 2 ? v[i].z : v[i].w;
+            h[i] = (_Float16)f;
+            m[i] = (_Float16)(f - (float)h[i]);
+        }
+        const size_t u = ((size_t)grp * C + c0 + c) * HW + n;
+        a.img[u] = __builtin_bit_cast(uint4, h);
+        if (a.NS == 2) a.img[plane + u] = __builtin_bit_cast(uint4, m);
+    }
+}
+
+struct WgradImgArgs {
+    const uint4* act;      // [NS][G][Cin][H * W]
+    const uint4* dy;       // [NS][G][Cout][H * W]
+    int Cin, Cout, H, W, G;
+    float* part;           // [P][Cout/64][Cin/32][64 co][9][32 ci]
+    int P;
+};
+
+template <int NS>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_img_kernel(const WgradImgArgs a) {
+    constexpr int TX = 8, TY = 2, NPX = 16, PW = 10, PH = 4, NHP = 40, CK = 32, TAPS = 9;
+    constexpr int APITCH = NHP + 1, DPITCH = NPX + 1;
+    constexpr int NA = NS * CK * NHP, ND = NS * 64 * NPX;                   // units per tile: 2560 + 2048 (NS = 2)
+    constexpr int LA = NA / 256, LD = ND / 256;                             // per thread: 10 + 8
+    __shared__ uint4 actL[NS][CK * APITCH];
+    __shared__ uint4 dyL[NS][64 * DPITCH];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cw = wave & 1, tg = wave >> 1;
+    const int r = lane & 15, g = lane >> 4;
+    const int nchunk = a.Cin / CK, ncb = a.Cout >> 6, HW = a.H * a.W;
+    int bid = blockIdx.x;
+    const int chunk = bid % nchunk; bid /= nchunk;
+    const int cb = bid % ncb;
+    const int p = bid / ncb;
+    const int tilesX = (a.W + TX - 1) / TX, tilesY = (a.H + TY - 1) / TY, tpg = tilesX * tilesY;
+    const int ntile = a.G * tpg;
+    const int t0 = (int)((long long)ntile * p / a.P), t1 = (int)((long long)ntile * (p + 1) / a.P);
+    const int tapbase = tg * 5, ntap = tg ? 4 : 5;
+    const size_t aplane = (size_t)a.G * a.Cin * HW, dplane = (size_t)a.G * a.Cout * HW;
+    wg_v4f acc[2][2][5];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int t = 0; t < 5; ++t) acc[i][j][t] = wg_v4f{0.f, 0.f, 0.f, 0.f};
+    uint4 ra[LA], rd[LD];
+    auto fetch = [&](int tile) {
+        const int grp = tile / tpg, tt = tile - grp * tpg;
+        const int y0 = (tt / tilesX) * TY, x0 = (tt % tilesX) * TX;
+#pragma unroll
+        for (int i = 0; i < LA; ++i) {
+            const int e = tid + 256 * i, s2 = e / (CK * NHP), rem = e - s2 * (CK * NHP), ch = rem / NHP, hp = rem - ch * NHP;
+            const int gy = y0 - 1 + hp / PW, gx = x0 - 1 + hp % PW;
+            ra[i] = make_uint4(0u, 0u, 0u, 0u);
+            if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
+                ra[i] = a.act[s2 * aplane + ((size_t)grp * a.Cin + chunk * CK + ch) * HW + gy * a.W + gx];
+        }
+#pragma unroll
+        for (int i = 0; i < LD; ++i) {
+            const int e = tid + 256 * i, s2 = e / (64 * NPX), rem = e - s2 * (64 * NPX), co = rem >> 4, n = rem & 15;
+            const int y = y0 + (n >> 3), x = x0 + (n & 7);
+            rd[i] = make_uint4(0u, 0u, 0u, 0u);
+            if (y < a.H && x < a.W) rd[i] = a.dy[s2 * dplane + ((size_t)grp * a.Cout + cb * 64 + co) * HW + y * a.W + x];
+        }
+    };
+    if (t0 < t1) fetch(t0);
+    for (int tile = t0; tile < t1; ++tile) {
+        __syncthreads();                          // the previous tile's fragments have been read
+#pragma unroll
+        for (int i = 0; i < LA; ++i) {
+            const int e = tid + 256 * i, s2 = e / (CK * NHP), rem = e - s2 * (CK * NHP), ch = rem / NHP, hp = rem - ch * NHP;
+            actL[s2][ch * APITCH + hp] = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < LD; ++i) {
+            const int e = tid + 256 * i, s2 = e / (64 * NPX), rem = e - s2 * (64 * NPX), co = rem >> 4, n = rem & 15;
+            dyL[s2][co * DPITCH + n] = rd[i];
+        }
+        __syncthreads();
+        if (tile + 1 < t1) fetch(tile + 1);       // in flight while this tile multiplies
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int ty = ks >> 1, tx = 4 * (ks & 1) + g;
+            wg_f16x8 fa[NS][2];
+#pragma unroll
+            for (int s2 = 0; s2 < NS; ++s2)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) fa[s2][i] = __builtin_bit_cast(wg_f16x8, dyL[s2][(cw * 32 + i * 16 + r) * DPITCH + ty * TX + tx]);
+#pragma unroll
+            for (int t = 0; t < 5; ++t) {
+                if (t < ntap) {
+                    const int tap = tapbase + t, ky = tap / 3, kx = tap - 3 * ky;
+                    wg_f16x8 fb[NS][2];
+#pragma unroll
+                    for (int s2 = 0; s2 < NS; ++s2)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            fb[s2][j] = __builtin_bit_cast(wg_f16x8, actL[s2][(j * 16 + r) * APITCH + (ty + ky) * PW + tx + kx]);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            if (NS == 2) {
+                                acc[i][j][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[NS - 1][i], fb[0][j], acc[i][j][t], 0, 0, 0);
+                                acc[i][j][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[0][i], fb[NS - 1][j], acc[i][j][t], 0, 0, 0);
+                            }
+                            acc[i][j][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[0][i], fb[0][j], acc[i][j][t], 0, 0, 0);
+                        }
+                }
+            }
+        }
+    }
+    float* o = a.part + ((((size_t)p * ncb + cb) * nchunk + chunk) * 64) * TAPS * CK;
+#pragma unroll
+    for (int t = 0; t < 5; ++t)
+        if (t < ntap) {
+            const int tap = tapbase + t;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        o[((size_t)(cw * 32 + i * 16 + 4 * g + e) * TAPS + tap) * CK + j * 16 + r] = acc[i][j][t][e];
+        }
+}
+
+// convolution weight-gradient family: CDDPM_WGRAD = h3 (default: fp16 two-term split, fp32-grade), h1 (plain fp16 operands), f32 (the
+// fp32-MFMA kernel above)
+int wgrad_mode() {
+    static int mode = -1;
+    if (mode < 0) {
+        const char* e = getenv("CDDPM_WGRAD");
+        mode = (e && !strcmp(e, "f32")) ? 0 : (e && !strcmp(e, "h1")) ? 1 : 2;
+    }
+    return mode;
+}
+
 // dW[co][ci][t] (PyTorch layout) = sum over the P partial tiles in the order of p
-__global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float* __restrict__ part, int P, int Cout, int Cin, int taps,
+__global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float* __restrict__ part, int P, int Cout, int Cin, int taps, int CK,
                                                                 float* __restrict__ dw) {
     const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
     if (e >= (long long)Cout * Cin * taps) return;
-    const int CK = (taps == 9) ? 32 : 64;
     const int t = (int)(e % taps);
     const int ci = (int)((e / taps) % Cin), co = (int)(e / ((long long)taps * Cin));
     const int ncb = Cout >> 6, nchunk = Cin / CK;
@@ -381,45 +744,84 @@ __global__ __launch_bounds__(256) void bias_grad_partial_kernel(const float* __r
     for (int c = tid; c < C; c += 256) part[(size_t)blockIdx.x * C + c] = red[c];
 }
 __global__ __launch_bounds__(256) void bias_grad_fold_kernel(const double* __restrict__ part, int nchunk, int C, float* __restrict__ db) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
+    // 64 channels per workgroup, the chunks in four interleaved slices (fixed order within a slice, slices folded in order)
+    __shared__ double red[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), sl = threadIdx.x >> 6;
     double t = 0;
-    for (int k = 0; k < nchunk; ++k) t += part[(size_t)k * C + c];
-    db[c] = (float)t;
+    if (c < C)
+        for (int k = sl; k < nchunk; k += 4) t += part[(size_t)k * C + c];
+    red[sl][threadIdx.x & 63] = t;
+    __syncthreads();
+    if (sl == 0 && c < C) db[c] = (float)(red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 // scratch: nchunk * C doubles, nchunk = bias_grad_chunks(npix, C, scratch floats available)
 int bias_grad_chunks(long long npix, int C, size_t scratch_floats) {
     long long n = (long long)(scratch_floats / 2 / (size_t)C);
-    if (n > 256) n = 256;
+    if (n > 512) n = 512;
     if (n > npix) n = npix;
     return n < 1 ? 1 : (int)n;
 }
 static void bias_grad_run(const float* dy, long long npix, int C, float* db, double* scratch, int nchunk, hipStream_t stream) {
     hipLaunchKernelGGL(bias_grad_partial_kernel, dim3(nchunk), dim3(256), 0, stream, dy, npix, C, nchunk, scratch);
-    hipLaunchKernelGGL(bias_grad_fold_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, scratch, nchunk, C, db);
+    hipLaunchKernelGGL(bias_grad_fold_kernel, dim3((C + 63) / 64), dim3(256), 0, stream, scratch, nchunk, C, db);
 }
 
 int conv_wgrad_parts(int B, int H, int W, int Cin, int Cout, int taps) {
     // enough workgroups for two per CU, at most one tile each, at least 1
-    const int ntile = B * (H / 4) * ((W + 31) / 32);
-    const int per = (Cout / 64) * (Cin / (taps == 9 ? 32 : 64));
+    // mirrors launch_conv_wgrad's choice of kernel: the split families tile (8 samples) x (2 x 8 pixels) and 32-channel chunks
+    const bool f32k = wgrad_mode() == 0 || (taps == 1 && Cin % 64 == 0 && H % 4 == 0 && H >= 4);
+    const int ntile = !f32k ? ((B + 7) / 8) * ((H + 1) / 2) * ((W + 7) / 8) : B * (H / 4) * ((W + 31) / 32);
+    const int per = (Cout / 64) * (Cin / ((taps == 9 || !f32k) ? 32 : 64));
     int P = (512 + per - 1) / per;
     if (P > ntile) P = ntile;
     if (P > 64) P = 64;
     return P < 1 ? 1 : P;
 }
 
+// scratch of the two-pass 3x3 family beyond the partial tiles: the two k-images, in 16-byte units (0: this call does not use them)
+size_t conv_wgrad_image_units(int B, int H, int W, int Cin, int Cout, int taps) {
+    const int mode = wgrad_mode();
+    if (mode == 0 || taps != 9) return 0;
+    return (size_t)(mode == 2 ? 2 : 1) * ((B + 7) / 8) * (size_t)(Cin + Cout) * H * W;
+}
+
 void launch_conv_wgrad(const float* x0, int C0, const float* x1, int C1, const float* coef, int silu, int up, const float* dy, int B, int H,
-                       int W, int Cout, int taps, float* part, int P, float* dw, float* db, hipStream_t stream) {
+                       int W, int Cout, int taps, float* part, int P, void* images, float* dw, float* db, hipStream_t stream) {
     WgradArgs a;
     a.x0 = x0; a.x1 = x1; a.C0 = C0; a.C1 = C1; a.coef = coef; a.silu = silu; a.up = up; a.dy = dy; a.B = B; a.H = H; a.W = W; a.Cout = Cout;
     a.part = part; a.P = P;
-    const int Cin = C0 + C1;
-    const unsigned grid = (unsigned)(P * (Cout / 64) * (Cin / (taps == 9 ? 32 : 64)));
-    if (taps == 9) hipLaunchKernelGGL(conv_wgrad_kernel<9>, dim3(grid), dim3(256), 0, stream, a);
-    else           hipLaunchKernelGGL(conv_wgrad_kernel<1>, dim3(grid), dim3(256), 0, stream, a);
+    const int Cin = C0 + C1, mode = wgrad_mode();
+    const int G = (B + 7) / 8;
+    int CK = 32;
+    if (mode != 0 && taps == 9) {
+        // pass 1: the two k-images; pass 2: the GEMM over them
+        const int NS = mode == 2 ? 2 : 1;
+        uint4* aimg = static_cast<uint4*>(images);
+        uint4* dimg = aimg + (size_t)NS * G * Cin * H * W;
+        ImageArgs ia;
+        ia.x0 = x0; ia.x1 = x1; ia.C0 = C0; ia.C1 = C1; ia.coef = coef; ia.silu = silu; ia.up = up; ia.B = B; ia.H = H; ia.W = W; ia.G = G;
+        ia.img = aimg; ia.NS = NS;
+        hipLaunchKernelGGL(wgrad_image_kernel, dim3((H * W + 7) / 8, (Cin + 127) / 128, G), dim3(256), 0, stream, ia);
+        ia.x0 = dy; ia.x1 = nullptr; ia.C0 = Cout; ia.C1 = 0; ia.coef = nullptr; ia.silu = 0; ia.up = 0; ia.img = dimg;
+        hipLaunchKernelGGL(wgrad_image_kernel, dim3((H * W + 7) / 8, (Cout + 127) / 128, G), dim3(256), 0, stream, ia);
+        WgradImgArgs w;
+        w.act = aimg; w.dy = dimg; w.Cin = Cin; w.Cout = Cout; w.H = H; w.W = W; w.G = G; w.part = part; w.P = P;
+        const unsigned grid = (unsigned)(P * (Cout / 64) * (Cin / 32));
+        if (NS == 2) hipLaunchKernelGGL(conv_wgrad_img_kernel<2>, dim3(grid), dim3(256), 0, stream, w);
+        else         hipLaunchKernelGGL(conv_wgrad_img_kernel<1>, dim3(grid), dim3(256), 0, stream, w);
+    } else if (mode == 0 || (taps == 1 && Cin % 64 == 0 && H % 4 == 0 && H >= 4 && (C1 == 0 || C0 % 64 == 0))) {
+        // fp32-MFMA kernel: the 1x1 convolutions (4 % of the weight-gradient FLOPs) run faster on it than on the single-pass split kernel
+        CK = taps == 9 ? 32 : 64;
+        const unsigned grid = (unsigned)(P * (Cout / 64) * (Cin / CK));
+        if (taps == 9) hipLaunchKernelGGL(conv_wgrad_kernel<9>, dim3(grid), dim3(256), 0, stream, a);
+        else           hipLaunchKernelGGL(conv_wgrad_kernel<1>, dim3(grid), dim3(256), 0, stream, a);
+    } else {
+        const unsigned grid = (unsigned)(P * (Cout / 64) * (Cin / 32));
+        if (mode == 1) hipLaunchKernelGGL((conv_wgrad_x_kernel<1, 1>), dim3(grid), dim3(256), 0, stream, a, G);
+        else           hipLaunchKernelGGL((conv_wgrad_x_kernel<1, 2>), dim3(grid), dim3(256), 0, stream, a, G);
+    }
     const long long n = (long long)Cout * Cin * taps;
-    hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, part, P, Cout, Cin, taps, dw);
+    hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, part, P, Cout, Cin, taps, CK, dw);
     if (db) {   // the partial tiles are folded by now (stream order): their memory serves as the bias sum's scratch
         const size_t part_floats = (size_t)P * Cout * Cin * taps;
         bias_grad_run(dy, (long long)B * H * W, Cout, db, reinterpret_cast<double*>(part), bias_grad_chunks((long long)B * H * W, Cout, part_floats), stream);
@@ -787,8 +1189,8 @@ __global__ __launch_bounds__(256) void loss_kernel(const float* __restrict__ out
     for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
     if (tid == 0) loss_b[b] = (float)(red[0] / HW * wb);
 }
-void launch_bias_grad(const float* dy, long long npix, int C, float* db, double* scratch /* 256 * C doubles */, hipStream_t stream) {
-    bias_grad_run(dy, npix, C, db, scratch, bias_grad_chunks(npix, C, (size_t)512 * C), stream);
+void launch_bias_grad(const float* dy, long long npix, int C, float* db, double* scratch /* 512 * C doubles */, hipStream_t stream) {
+    bias_grad_run(dy, npix, C, db, scratch, bias_grad_chunks(npix, C, (size_t)1024 * C), stream);
 }
 void launch_loss(const float* out, const float* target, const float* w_b, int l2, int B, int HW, float grad_scale, float* dout, float* loss_b,
                  hipStream_t stream) {

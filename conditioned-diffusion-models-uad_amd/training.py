@@ -128,6 +128,13 @@ class UNetTrainer:
             nmid = (H >> (len(self.mult) - 1)) * (W >> (len(self.mult) - 1))
             cmid = self.mult[-1] * self.C
             arena = 2 * B * (cmid // 64) * nmid * nmid * 4 + (192 << 20)
+            # the 3x3 weight gradient's two k-images (fp16 hi | mid, batch padded to groups of 8): the largest (Cin + Cout) x pixels of the net
+            lv, worst = 0, 0
+            for kind, _name, a_ in self.program:
+                if kind == "res":
+                    worst = max(worst, (a_["cin"] + a_["cout"]) * (H >> lv) * (W >> lv), 2 * a_["cout"] * (H >> lv) * (W >> lv))
+                    lv += 1 if a_["kind"] == "down" else -1 if a_["kind"] == "up" else 0
+            arena += 2 * ((B + 7) // 8) * worst * 16
             rc = self.eng.lib.cddpm_op_set_scratch(self.eng._h, arena)
             if rc != 0:
                 raise RuntimeError("cddpm_op_set_scratch failed: " + self.eng.lib.cddpm_last_error(self.eng._h).decode())

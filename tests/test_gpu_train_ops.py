@@ -153,3 +153,26 @@ def test_device_weight_packer_is_the_host_packer(eng, Cout, Cin, k):
         assert rc == 0, lib.cddpm_last_error(eng._h)
         torch.cuda.synchronize()
         assert np.array_equal(dev.cpu().numpy(), host), (mode, int((dev.cpu().numpy() != host).sum()))
+
+
+@pytest.mark.parametrize("B,C0,Cout,k,H,W,up", [(11, 128, 128, 3, 6, 20, False), (16, 128, 64, 1, 8, 8, False), (9, 128, 128, 3, 8, 16, True),
+                                                (8, 256, 128, 3, 5, 9, False)])
+def test_conv_wgrad_batch_groups_and_ragged_tiles(eng, B, C0, Cout, k, H, W, up):
+    """the 16-bit-pipe weight-gradient kernel contracts over (pixel, sample mod 8): batches that do not fill their last group of 8,
+    images that do not fill their last 2 x 8 pixel tile, and the upsampled input of an 'up' ResBlock's first convolution"""
+    torch.manual_seed(B + C0 + Cout + H)
+    hs, ws = (H // 2, W // 2) if up else (H, W)
+    x = torch.randn(B, C0, hs, ws, dtype=torch.float64)
+    coef = torch.stack([torch.randn(B, C0) * 0.2, 1 + 0.2 * torch.randn(B, C0), torch.randn(B, C0) * 0.2]).double()
+    a = F.silu((x - coef[0][:, :, None, None]) * coef[1][:, :, None, None] + coef[2][:, :, None, None])
+    if up:
+        a = F.interpolate(a, scale_factor=2, mode="nearest")
+    w = (torch.randn(Cout, C0, k, k, dtype=torch.float64) / (C0 * k * k) ** 0.5).requires_grad_(True)
+    bias = torch.zeros(Cout, dtype=torch.float64, requires_grad=True)
+    dy = torch.randn(B, Cout, H, W, dtype=torch.float64)
+    F.conv2d(a, w, bias, padding=k // 2).backward(dy)
+    dw, db = eng.op_conv_wgrad(nhwc(x), None, coef.float().cuda(), True, nhwc(dy), ksize=k, upsample=up)
+    ew = float((dw.double().cpu() - w.grad).abs().max() / w.grad.abs().max())
+    eb = float((db.double().cpu() - bias.grad).abs().max() / bias.grad.abs().max())
+    print(B, C0, Cout, k, H, W, up, f"dW rel {ew:.2e}  db rel {eb:.2e}")
+    assert ew < 1e-5 and eb < 1e-5

@@ -292,7 +292,7 @@ def test_split_weight_image_reproduces_the_weights():
     w = (rng.standard_normal((Cout, Cin, 3, 3)) * 0.05).astype(np.float32)
     w.flat[:10] = [0.0, -0.0, 0.25, -0.25, 3.0e-20, 0.2, 0.1 + 2.0 ** -23, -(2.0 ** -100), 0.1, 0.25 - 2.0 ** -26]
     n = lib.cddpm_packed_conv_bytes(Cout, Cin, taps)
-    assert lib.cddpm_packed_conv_bytes(100, Cin, taps) == 0 and lib.cddpm_packed_conv_bytes(Cout, Cin, 4) == 0
+    assert lib.cddpm_packed_conv_bytes(100, Cin, taps) == 0 and lib.cddpm_packed_conv_bytes(Cout, Cin, 5) == 0
     buf = (ctypes.c_uint8 * n)()
     wexp = ctypes.c_int(-1)
     fmt = lib.cddpm_pack_conv_weights(w.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), Cout, Cin, taps, buf, ctypes.byref(wexp))
