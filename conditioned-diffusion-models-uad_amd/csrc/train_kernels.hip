@@ -525,8 +525,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x_kernel(const WgradArgs a,
 // [plane][batch group][channel][y][x][8 samples] (16-byte units) -- so the transform and the SiLU are paid once per element instead of
 // once per (output-channel block x halo overlap) as in conv_wgrad_x_kernel above; (2) conv_wgrad_img_kernel is then a pure fp16 GEMM
 // over those images: staging is 16-byte copies (a 10-pixel halo row = 160 contiguous bytes), the next tile's units are fetched into
-// registers while the current tile's MFMAs run, and two workgroups share a CU. Same tile, wave roles, k order and partial layout as
-// conv_wgrad_x_kernel; the images cost one extra write + read of each operand (= its fp32 size per pass), ~1 % of the kernel's time.
+// registers while the current tile's MFMAs run, and two workgroups share a CU. Same tile, k order and partial layout as conv_wgrad_x_kernel (wave = co 32-block x ci 16-block, all nine taps); the images cost one extra write + read of each operand (= its fp32 size per pass), ~1 % of the kernel's time.
 // ------------------------------------------------------------------------------------------------------------------
 struct ImageArgs {
     const float* x0; const float* x1; int C0, C1;
@@ -597,7 +596,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_img_kernel(const WgradImgAr
     __shared__ uint4 actL[NS][CK * APITCH];
     __shared__ uint4 dyL[NS][64 * DPITCH];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int cw = wave & 1, tg = wave >> 1;
+    const int cw = wave & 1, cj = wave >> 1;          // wave = (co 32-block) x (ci 16-block), all nine taps: 18 accumulator tiles of 16 x 16
     const int r = lane & 15, g = lane >> 4;
     const int nchunk = a.Cin / CK, ncb = a.Cout >> 6, HW = a.H * a.W;
     int bid = blockIdx.x;
@@ -607,15 +606,12 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_img_kernel(const WgradImgAr
     const int tilesX = (a.W + TX - 1) / TX, tilesY = (a.H + TY - 1) / TY, tpg = tilesX * tilesY;
     const int ntile = a.G * tpg;
     const int t0 = (int)((long long)ntile * p / a.P), t1 = (int)((long long)ntile * (p + 1) / a.P);
-    const int tapbase = tg * 5, ntap = tg ? 4 : 5;
     const size_t aplane = (size_t)a.G * a.Cin * HW, dplane = (size_t)a.G * a.Cout * HW;
-    wg_v4f acc[2][2][5];
+    wg_v4f acc[2][9];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int t = 0; t < 5; ++t) acc[i][j][t] = wg_v4f{0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < 9; ++t) acc[i][t] = wg_v4f{0.f, 0.f, 0.f, 0.f};
     uint4 ra[LA], rd[LD];
     auto fetch = [&](int tile) {
         const int grp = tile / tpg, tt = tile - grp * tpg;
@@ -651,8 +647,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_img_kernel(const WgradImgAr
         }
         __syncthreads();
         if (tile + 1 < t1) fetch(tile + 1);       // in flight while this tile multiplies
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll 1
+        for (int ks = 0; ks < 4; ++ks) {      // not unrolled: the compiler otherwise hoists all 44 fragment reads and spills
             const int ty = ks >> 1, tx = 4 * (ks & 1) + g;
             wg_f16x8 fa[NS][2];
 #pragma unroll
@@ -660,42 +656,31 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_img_kernel(const WgradImgAr
 #pragma unroll
                 for (int i = 0; i < 2; ++i) fa[s2][i] = __builtin_bit_cast(wg_f16x8, dyL[s2][(cw * 32 + i * 16 + r) * DPITCH + ty * TX + tx]);
 #pragma unroll
-            for (int t = 0; t < 5; ++t) {
-                if (t < ntap) {
-                    const int tap = tapbase + t, ky = tap / 3, kx = tap - 3 * ky;
-                    wg_f16x8 fb[NS][2];
+            for (int t = 0; t < 9; ++t) {
+                const int ky = t / 3, kx = t - 3 * ky;
+                wg_f16x8 fb[NS];
 #pragma unroll
-                    for (int s2 = 0; s2 < NS; ++s2)
+                for (int s2 = 0; s2 < NS; ++s2)
+                    fb[s2] = __builtin_bit_cast(wg_f16x8, actL[s2][(cj * 16 + r) * APITCH + (ty + ky) * PW + tx + kx]);
 #pragma unroll
-                        for (int j = 0; j < 2; ++j)
-                            fb[s2][j] = __builtin_bit_cast(wg_f16x8, actL[s2][(j * 16 + r) * APITCH + (ty + ky) * PW + tx + kx]);
-#pragma unroll
-                    for (int i = 0; i < 2; ++i)
-#pragma unroll
-                        for (int j = 0; j < 2; ++j) {
-                            if (NS == 2) {
-                                acc[i][j][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[NS - 1][i], fb[0][j], acc[i][j][t], 0, 0, 0);
-                                acc[i][j][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[0][i], fb[NS - 1][j], acc[i][j][t], 0, 0, 0);
-                            }
-                            acc[i][j][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[0][i], fb[0][j], acc[i][j][t], 0, 0, 0);
-                        }
+                for (int i = 0; i < 2; ++i) {
+                    if (NS == 2) {
+                        acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[NS - 1][i], fb[0], acc[i][t], 0, 0, 0);
+                        acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[0][i], fb[NS - 1], acc[i][t], 0, 0, 0);
+                    }
+                    acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[0][i], fb[0], acc[i][t], 0, 0, 0);
                 }
             }
         }
     }
     float* o = a.part + ((((size_t)p * ncb + cb) * nchunk + chunk) * 64) * TAPS * CK;
 #pragma unroll
-    for (int t = 0; t < 5; ++t)
-        if (t < ntap) {
-            const int tap = tapbase + t;
+    for (int t = 0; t < 9; ++t)
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        o[((size_t)(cw * 32 + i * 16 + 4 * g + e) * TAPS + tap) * CK + j * 16 + r] = acc[i][j][t][e];
-        }
+            for (int e = 0; e < 4; ++e)
+                o[((size_t)(cw * 32 + i * 16 + 4 * g + e) * TAPS + t) * CK + cj * 16 + r] = acc[i][t][e];
 }
 
 // convolution weight-gradient family: CDDPM_WGRAD = h3 (default: fp16 two-term split, fp32-grade), h1 (plain fp16 operands), f32 (the
@@ -744,15 +729,19 @@ __global__ __launch_bounds__(256) void bias_grad_partial_kernel(const float* __r
     for (int c = tid; c < C; c += 256) part[(size_t)blockIdx.x * C + c] = red[c];
 }
 __global__ __launch_bounds__(256) void bias_grad_fold_kernel(const double* __restrict__ part, int nchunk, int C, float* __restrict__ db) {
-    // 64 channels per workgroup, the chunks in four interleaved slices (fixed order within a slice, slices folded in order)
-    __shared__ double red[4][64];
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63), sl = threadIdx.x >> 6;
+    // 16 channels per workgroup, the chunks in 16 interleaved slices (fixed order within a slice, slices folded in order)
+    __shared__ double red[16][17];
+    const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4, c = blockIdx.x * 16 + cl;
     double t = 0;
     if (c < C)
-        for (int k = sl; k < nchunk; k += 4) t += part[(size_t)k * C + c];
-    red[sl][threadIdx.x & 63] = t;
+        for (int k = sl; k < nchunk; k += 16) t += part[(size_t)k * C + c];
+    red[sl][cl] = t;
     __syncthreads();
-    if (sl == 0 && c < C) db[c] = (float)(red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+    if (sl == 0 && c < C) {
+        double u = 0;
+        for (int k = 0; k < 16; ++k) u += red[k][cl];
+        db[c] = (float)u;
+    }
 }
 // scratch: nchunk * C doubles, nchunk = bias_grad_chunks(npix, C, scratch floats available)
 int bias_grad_chunks(long long npix, int C, size_t scratch_floats) {
@@ -763,7 +752,7 @@ int bias_grad_chunks(long long npix, int C, size_t scratch_floats) {
 }
 static void bias_grad_run(const float* dy, long long npix, int C, float* db, double* scratch, int nchunk, hipStream_t stream) {
     hipLaunchKernelGGL(bias_grad_partial_kernel, dim3(nchunk), dim3(256), 0, stream, dy, npix, C, nchunk, scratch);
-    hipLaunchKernelGGL(bias_grad_fold_kernel, dim3((C + 63) / 64), dim3(256), 0, stream, scratch, nchunk, C, db);
+    hipLaunchKernelGGL(bias_grad_fold_kernel, dim3((C + 15) / 16), dim3(256), 0, stream, scratch, nchunk, C, db);
 }
 
 int conv_wgrad_parts(int B, int H, int W, int Cin, int Cout, int taps) {

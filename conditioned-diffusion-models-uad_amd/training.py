@@ -459,7 +459,7 @@ def all_reduce_sum_(flat: torch.Tensor) -> int:
     gradient buffer (43.9 M floats = 176 MB: a single large ring collective, what xGMI's per-link bandwidth wants). Returns the number of
     ranks summed over; the caller divides (training_step folds it into Adam's unscale factor)."""
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized():
         dist.all_reduce(flat)
         return dist.get_world_size()
     return 1

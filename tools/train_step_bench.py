@@ -1,6 +1,7 @@
 """Times the training step (training.py: forward + loss + backward + Adam, all on the HIP operators) on one GPU.
     python tools/train_step_bench.py [--batch 16] [--size 128] [--steps 5] [--warmup 2]
-BASELINE config 5 is 128x1x128x128 over 8 GPUs data-parallel = 16 slices per GPU and step."""
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 tools/train_step_bench.py   (data-parallel, RCCL)
+BASELINE config 5 is 128x1x128x128 over 8 GPUs data-parallel = 16 slices per GPU and step (weak scaling: --batch is per rank)."""
 import argparse
 import importlib
 import json
@@ -25,26 +26,38 @@ def main():
     a = ap.parse_args()
     tr = importlib.import_module(PKG + ".training")
     synth = importlib.import_module(PKG + ".synth")
-    dev = torch.device("cuda", 0)
+    world, rank, local = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    ddp = "RANK" in os.environ                   # under torchrun (also with one rank: the RCCL path runs)
+    if ddp:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
     sd = synth.synth_state_dict(0)
     trainer = tr.UNetTrainer({k: torch.from_numpy(v) for k, v in sd.items()}, device=dev)
     B, S, T = a.batch, a.size, 1000
-    x01 = torch.from_numpy(synth.synth_slices(1, 0, B, S, S)).reshape(B, 1, S, S).to(dev)
-    cond = torch.from_numpy(synth.synth_cond(1, 0, B)).to(dev)
-    noise = torch.from_numpy(synth.noise_xT(1, 0, B, S, S)).reshape(B, 1, S, S).to(dev)
+    x01 = torch.from_numpy(synth.synth_slices(1, rank * B, B, S, S)).reshape(B, 1, S, S).to(dev)      # each rank its own slices
+    cond = torch.from_numpy(synth.synth_cond(1, rank * B, B)).to(dev)
+    noise = torch.from_numpy(synth.noise_xT(1, rank * B, B, S, S)).reshape(B, 1, S, S).to(dev)
     t = torch.tensor([(137 * (i + 1)) % T for i in range(B)], dtype=torch.long, device=dev)
     losses = []
     for _ in range(a.warmup):
-        losses.append(float(tr.training_step(trainer, x01, cond, t=t, noise=noise, objective="pred_noise", loss_type="l2")))
+        losses.append(float(tr.training_step(trainer, x01, cond, t=t, noise=noise, objective="pred_noise", loss_type="l2", all_reduce=ddp)))
     torch.cuda.synchronize()
+    if ddp:
+        dist.barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        loss = tr.training_step(trainer, x01, cond, t=t, noise=noise, objective="pred_noise", loss_type="l2")
+        loss = tr.training_step(trainer, x01, cond, t=t, noise=noise, objective="pred_noise", loss_type="l2", all_reduce=ddp)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / a.steps
+    if ddp:
+        tmax = torch.tensor([dt], device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax)
     losses.append(float(loss))
     res = {"workload": f"training step {B}x1x{S}x{S} (noise-pred MSE, fp32-emulated convolutions, Adam)", "ms_per_step": dt * 1e3,
-           "slices_per_s": B / dt, "losses": losses, "peak_mem_GB": torch.cuda.max_memory_allocated() / 2 ** 30}
+           "slices_per_s": world * B / dt, "n_gpus": world, "losses": losses, "peak_mem_GB": torch.cuda.max_memory_allocated() / 2 ** 30}
     if a.phases:
         buf = importlib.import_module(PKG + ".schedule").schedule_buffers(T)
         x0 = x01 * 2 - 1
@@ -61,7 +74,11 @@ def main():
             torch.cuda.synchronize(); t3 = time.perf_counter()
             ph = {"forward_ms": (t1 - t0) * 1e3, "loss_backward_ms": (t2 - t1) * 1e3, "adam_repack_ms": (t3 - t2) * 1e3}
         res["phases"] = ph
-    print(json.dumps(res))
+    if rank == 0:
+        print(json.dumps(res))
+    if ddp:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":
