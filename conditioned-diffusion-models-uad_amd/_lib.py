@@ -84,7 +84,7 @@ SYMBOLS = {
     "cddpm_op_linear_backward": (_i, [_vp, _fp, _fp, _fp, _i, _i, _i, _i, _fp, _fp, _fp, _vp]),
     "cddpm_op_linear": (_i, [_vp, _fp, _fp, _fp, _i, _i, _i, _i, _fp, _vp]),
     "cddpm_op_conv_in1": (_i, [_vp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _vp]),
-    "cddpm_op_head": (_i, [_vp, _fp, _fp, _fp, C.c_float, _fp, _i, _i, _i, _i, _vp]),
+    "cddpm_op_head": (_i, [_vp, _fp, _fp, _fp, C.c_float, _fp, _fp, _i, _i, _i, _i, _vp]),
     "cddpm_op_pool_act": (_i, [_vp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _vp]),
     "cddpm_op_unpool2": (_i, [_vp, _fp, _fp, _i, _i, _i, _i, C.c_float, _i, _vp]),
     "cddpm_op_sumpool2": (_i, [_vp, _fp, _fp, _i, _i, _i, _i, _i, _vp]),

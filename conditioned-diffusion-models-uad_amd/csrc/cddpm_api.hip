@@ -727,7 +727,7 @@ int forward_impl(cddpm_ctx* h, const float* x, float* out, int B, int H, int W, 
                 if (gn_coef(h, cur, curC, nullptr, 0, B, H * W, h->out_norm, false, 0, s)) return -1;
                 Prof ph(h, PC_OTHER, 18.0 * B * H * W * curC, 4.0 * B * (double)H * W * (curC + 19), s);
                 launch_head_dots(cur, h->coef, h->head_w9, h->headP, B, H * W, curC, s);
-                launch_head_gather(h->headP, h->head_bias, out, B, H, W, s);
+                launch_head_gather(h->headP, h->head_bias, nullptr, out, B, H, W, s);
                 dst = nullptr;
                 break;
             }
@@ -1670,14 +1670,14 @@ int cddpm_op_conv_in1(cddpm_handle h, const float* x_dev, const float* w_dev, co
     launch_conv_in1(x_dev, w_dev, b_dev, out_dev, B, H, W, C, s);
     OP_EPILOGUE()
 }
-int cddpm_op_head(cddpm_handle h, const float* x_dev, const float* coef_dev, const float* w9_dev, float bias, float* out_dev, int B,
-                  int H, int W, int C, void* stream) {
+int cddpm_op_head(cddpm_handle h, const float* x_dev, const float* coef_dev, const float* w9_dev, float bias, const float* bias_dev,
+                  float* out_dev, int B, int H, int W, int C, void* stream) {
     OP_PROLOGUE(x_dev && coef_dev && w9_dev && out_dev && C % 32 == 0, "cddpm_op_head: bad arguments")
     OpScratch sc(h, s);
     float* P = sc.n<float>((size_t)B * H * W * 9);
     SCRATCH_CHECK(sc)
     launch_head_dots(x_dev, coef_dev, w9_dev, P, B, H * W, C, s);
-    launch_head_gather(P, bias, out_dev, B, H, W, s);
+    launch_head_gather(P, bias, bias_dev, out_dev, B, H, W, s);
     OP_EPILOGUE()
 }
 int cddpm_op_pool_act(cddpm_handle h, const float* x_dev, const float* coef_dev, float* hp_dev, float* xp_dev, int B, int H, int W, int C,

@@ -99,7 +99,8 @@ void launch_conv_in1(const float* x, const float* w, const float* bias, float* o
 // head: per pixel 9 partial dot products of act(x) with w[tap][C] -> P[B,HW,9]; then gather to out [B,H,W]
 void launch_head_dots(const float* x, const float* coef, const float* w9 /*[9][C]*/, float* P, int B, int HW, int C,
                       hipStream_t stream);
-void launch_head_gather(const float* P, float bias, float* out, int B, int H, int W, hipStream_t stream);
+void launch_head_gather(const float* P, float bias, const float* bias_ptr /* device, overrides bias */, float* out, int B, int H, int W,
+                        hipStream_t stream);
 // down ResBlock front end: hp = avgpool2(silu(affine(x))), xp = avgpool2(x); NHWC
 void launch_pool_act(const float* x, const float* coef, float* hp, float* xp, int B, int H, int W, int C,
                      hipStream_t stream);

@@ -137,14 +137,14 @@ void launch_head_dots(const float* x, const float* coef, const float* w9, float*
                        HW, C);
 }
 
-__global__ __launch_bounds__(256) void head_gather_kernel(const float* __restrict__ P, float bias,
+__global__ __launch_bounds__(256) void head_gather_kernel(const float* __restrict__ P, float bias, const float* __restrict__ bias_ptr,
                                                           float* __restrict__ out, int B, int H, int W) {
     const long long total = (long long)B * H * W;
     const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
     if (p >= total) return;
     const int xx = (int)(p % W);
     const int yy = (int)((p / W) % H);
-    float acc = bias;
+    float acc = bias_ptr ? bias_ptr[0] : bias;
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
@@ -155,9 +155,9 @@ __global__ __launch_bounds__(256) void head_gather_kernel(const float* __restric
     out[p] = acc;
 }
 
-void launch_head_gather(const float* P, float bias, float* out, int B, int H, int W, hipStream_t stream) {
+void launch_head_gather(const float* P, float bias, const float* bias_ptr, float* out, int B, int H, int W, hipStream_t stream) {
     const long long total = (long long)B * H * W;
-    hipLaunchKernelGGL(head_gather_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, P, bias, out, B,
+    hipLaunchKernelGGL(head_gather_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, P, bias, bias_ptr, out, B,
                        H, W);
 }
 

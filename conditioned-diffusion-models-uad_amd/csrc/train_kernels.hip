@@ -590,7 +590,10 @@ struct WgradImgArgs {
 template <int NS>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_img_kernel(const WgradImgArgs a) {
     constexpr int TX = 8, TY = 2, NPX = 16, PW = 10, PH = 4, NHP = 40, CK = 32, TAPS = 9;
-    constexpr int APITCH = NHP + 1, DPITCH = NPX + 1;
+    // 16-byte units per channel row: pitch = 2 (mod 8). ds_read_b128 serves a wave in four groups of 16 lanes, each holding the 16 channel
+    // rows of a fragment once, 8 of them (r) at k-group g and the other 8 (r + 8) at g + 1: rows r and r + 8 then share an even 16-byte bank
+    // slot, and the +1 of the second half moves it to the odd one -- conflict-free (a pitch of 41 measured 41 % conflict cycles)
+    constexpr int APITCH = NHP + 2, DPITCH = NPX + 2;
     constexpr int NA = NS * CK * NHP, ND = NS * 64 * NPX;                   // units per tile: 2560 + 2048 (NS = 2)
     constexpr int LA = NA / 256, LD = ND / 256;                             // per thread: 10 + 8
     __shared__ uint4 actL[NS][CK * APITCH];
@@ -599,10 +602,11 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_img_kernel(const WgradImgAr
     const int cw = wave & 1, cj = wave >> 1;          // wave = (co 32-block) x (ci 16-block), all nine taps: 18 accumulator tiles of 16 x 16
     const int r = lane & 15, g = lane >> 4;
     const int nchunk = a.Cin / CK, ncb = a.Cout >> 6, HW = a.H * a.W;
-    int bid = blockIdx.x;
-    const int chunk = bid % nchunk; bid /= nchunk;
-    const int cb = bid % ncb;
-    const int p = bid / ncb;
+    // workgroups go round-robin over the 8 XCDs (each with its own L2): the ncb x nchunk workgroups of one pixel range p share its dy tiles
+    // (across ci chunks) and act tiles (across co blocks), so they are numbered to run on ONE XCD at the same time. P is a multiple of 8.
+    const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3, per = ncb * nchunk;
+    const int inner = jj % per, chunk = inner % nchunk, cb = inner / nchunk;
+    const int p = (jj / per) * 8 + xcd;
     const int tilesX = (a.W + TX - 1) / TX, tilesY = (a.H + TY - 1) / TY, tpg = tilesX * tilesY;
     const int ntile = a.G * tpg;
     const int t0 = (int)((long long)ntile * p / a.P), t1 = (int)((long long)ntile * (p + 1) / a.P);
@@ -655,21 +659,30 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_img_kernel(const WgradImgAr
             for (int s2 = 0; s2 < NS; ++s2)
 #pragma unroll
                 for (int i = 0; i < 2; ++i) fa[s2][i] = __builtin_bit_cast(wg_f16x8, dyL[s2][(cw * 32 + i * 16 + r) * DPITCH + ty * TX + tx]);
+            // fragments of tap t + 1 are read while tap t multiplies
+            wg_f16x8 fb[2][NS];
+#pragma unroll
+            for (int s2 = 0; s2 < NS; ++s2) fb[0][s2] = __builtin_bit_cast(wg_f16x8, actL[s2][(cj * 16 + r) * APITCH + ty * PW + tx]);
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
-                const int ky = t / 3, kx = t - 3 * ky;
-                wg_f16x8 fb[NS];
+                if (t < 8) {
+                    const int ky = (t + 1) / 3, kx = (t + 1) - 3 * ky;
 #pragma unroll
-                for (int s2 = 0; s2 < NS; ++s2)
-                    fb[s2] = __builtin_bit_cast(wg_f16x8, actL[s2][(cj * 16 + r) * APITCH + (ty + ky) * PW + tx + kx]);
+                    for (int s2 = 0; s2 < NS; ++s2)
+                        fb[(t + 1) & 1][s2] = __builtin_bit_cast(wg_f16x8, actL[s2][(cj * 16 + r) * APITCH + (ty + ky) * PW + tx + kx]);
+                }
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     if (NS == 2) {
-                        acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[NS - 1][i], fb[0], acc[i][t], 0, 0, 0);
-                        acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[0][i], fb[NS - 1], acc[i][t], 0, 0, 0);
+                        acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[NS - 1][i], fb[t & 1][0], acc[i][t], 0, 0, 0);
+                        acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[0][i], fb[t & 1][NS - 1], acc[i][t], 0, 0, 0);
                     }
-                    acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[0][i], fb[0], acc[i][t], 0, 0, 0);
+                    acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[0][i], fb[t & 1][0], acc[i][t], 0, 0, 0);
                 }
+                // keep the program order "reads of tap t + 1, then the MFMAs of tap t" (the scheduler otherwise clusters the reads of two
+                // taps right in front of their MFMAs and the LDS latency is exposed every 12 MFMAs)
+                if (t < 8) __builtin_amdgcn_sched_group_barrier(0x100, NS, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, NS == 2 ? 6 : 2, 0);
             }
         }
     }
@@ -764,7 +777,9 @@ int conv_wgrad_parts(int B, int H, int W, int Cin, int Cout, int taps) {
     int P = (512 + per - 1) / per;
     if (P > ntile) P = ntile;
     if (P > 64) P = 64;
-    return P < 1 ? 1 : P;
+    if (P < 1) P = 1;
+    if (wgrad_mode() != 0 && taps == 9) P = (P + 7) & ~7;      // the two-pass kernel spreads its pixel ranges over the 8 XCDs
+    return P;
 }
 
 // scratch of the two-pass 3x3 family beyond the partial tiles: the two k-images, in 16-byte units (0: this call does not use them)

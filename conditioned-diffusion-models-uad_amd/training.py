@@ -272,9 +272,10 @@ class UNetTrainer:
         x = x.contiguous().float()
         # timestep embedding (util.py:151-171): cos first, float32 arithmetic as torch does
         half = self.C // 2
-        freqs = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float32) / half)
-        args = t.detach().cpu().float()[:, None] * freqs[None]
-        temb = torch.cat([torch.cos(args), torch.sin(args)], dim=-1).to(self.dev)
+        if not hasattr(self, "_freqs"):
+            self._freqs = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float32) / half).to(self.dev)
+        args = t.to(self.dev).float()[:, None] * self._freqs[None]          # on the device: no read-back of t (B x 64 values of plumbing)
+        temb = torch.cat([torch.cos(args), torch.sin(args)], dim=-1).contiguous()
         y1 = self.linear(temb, "time_embed.0")
         et = self.linear(y1, "time_embed.2", silu_in=True)
         cond = cond.float().contiguous()
@@ -336,7 +337,7 @@ class UNetTrainer:
                 coefo = self.gn_coef(cur, None, "out.0")
                 w9 = p["out.2.weight"].reshape(a["c"], 9).t().contiguous()
                 out = self._new(B, 1, H, W)
-                self._ck(self.lib.cddpm_op_head(self.h, _p(cur), _p(coefo), _p(w9), C.c_float(float(p["out.2.bias"][0])), _p(out), B, H, W, a["c"],
+                self._ck(self.lib.cddpm_op_head(self.h, _p(cur), _p(coefo), _p(w9), C.c_float(0.0), _p(p["out.2.bias"]), _p(out), B, H, W, a["c"],
                                                 self._s()), "op_head")
                 sv["out"] = dict(x=cur, coefo=coefo, w9=w9)
                 cur = out

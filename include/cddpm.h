@@ -277,8 +277,8 @@ int cddpm_op_linear(cddpm_handle h, const float* x_dev, const float* w_dev, cons
                     float* y_dev, void* stream);
 int cddpm_op_conv_in1(cddpm_handle h, const float* x_dev, const float* w_dev, const float* b_dev, float* out_dev, int B, int H, int W,
                       int C, void* stream);
-int cddpm_op_head(cddpm_handle h, const float* x_dev, const float* coef_dev, const float* w9_dev, float bias, float* out_dev, int B,
-                  int H, int W, int C, void* stream);
+int cddpm_op_head(cddpm_handle h, const float* x_dev, const float* coef_dev, const float* w9_dev, float bias, const float* bias_dev,
+                  float* out_dev, int B, int H, int W, int C, void* stream);   /* bias_dev (device, 1 float) overrides bias when given */
 int cddpm_op_pool_act(cddpm_handle h, const float* x_dev, const float* coef_dev, float* hp_dev, float* xp_dev, int B, int H, int W, int C,
                       void* stream);
 /* resampling backward and accumulation: dx[B,H,W,C] (+)= scale * dyp[B,H/2,W/2,C] at (y/2, x/2) (AvgPool2d(2) backward: scale 1/4);
