@@ -254,62 +254,60 @@ __global__ void add_int_kernel(int* p, int n, int v) {
 }
 // ---- split-K combine (small batches): out = ((plane 0 + plane 1) + ... ) + bias + residual, fixed order -> deterministic and
 //      independent of the batch; optional GroupNorm statistics records of `out` (one per 64 consecutive pixels).
-// One workgroup = 64 pixels x all channels: thread = (channel quad cq, pixel lane pl); a thread walks pixels pl, pl + npl, ...
+// One workgroup = 64 pixels x 64 channels (blockIdx.z = channel slice): thread = (channel quad cq of 16, pixel lane pl of 16), four
+// pixels per thread -- a 32 x 32 layer of a 4-slice batch is 256 workgroups with 4 x ksplit loads in flight per thread (the first
+// version gave a workgroup all channels of its 64 pixels: 64 workgroups, 16 x ksplit dependent loads per thread, 23 us per launch
+// and 19 % of a B = 4 reverse step).
 __global__ __launch_bounds__(256) void conv_reduce_kernel(const float* __restrict__ planes, int ksplit, const float* __restrict__ bias,
                                                           const float* __restrict__ res, int res_up, float* __restrict__ out,
                                                           float* __restrict__ stats, int H, int W, int Cout, size_t plane_elems) {
     __shared__ float4 red_s[256], red_q[256];
     const int tid = threadIdx.x, b = blockIdx.y, HW = H * W;
-    const int cqn = Cout >> 2;
     const int p0 = blockIdx.x * 64;
     const int nrec = gridDim.x;
-    for (int cq0 = 0; cq0 < cqn; cq0 += 256) {                   // (Cout <= 1024: one pass)
-        const int span = min(256, cqn - cq0);                    // channel quads of this pass
-        const int npl = 256 / span;                              // pixel lanes (>= 1)
-        const int cq = cq0 + tid % span, pl = tid / span;
-        float4 ssum = make_float4(0.f, 0.f, 0.f, 0.f), ssq = ssum;
-        if (pl < npl) {
-            const float4 bs = bias ? *reinterpret_cast<const float4*>(bias + 4 * cq) : make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int p = p0 + pl; p < min(HW, p0 + 64); p += npl) {
-                const size_t idx = ((size_t)b * HW + p) * Cout + 4 * cq;
-                float4 v = *reinterpret_cast<const float4*>(planes + idx);
-                for (int j = 1; j < ksplit; ++j) {
-                    const float4 w = *reinterpret_cast<const float4*>(planes + (size_t)j * plane_elems + idx);
-                    v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
-                }
-                v.x += bs.x; v.y += bs.y; v.z += bs.z; v.w += bs.w;
-                if (res) {
-                    const int y = p / W, x = p - y * W;
-                    const size_t rp = res_up ? ((size_t)(b * (H >> 1) + (y >> 1)) * (W >> 1) + (x >> 1)) : ((size_t)b * HW + p);
-                    const float4 r = *reinterpret_cast<const float4*>(res + rp * Cout + 4 * cq);
-                    v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
-                }
-                *reinterpret_cast<float4*>(out + idx) = v;
-                ssum.x += v.x; ssum.y += v.y; ssum.z += v.z; ssum.w += v.w;
-                ssq.x += v.x * v.x; ssq.y += v.y * v.y; ssq.z += v.z * v.z; ssq.w += v.w * v.w;
-            }
+    const int cq = blockIdx.z * 16 + (tid & 15), pl = tid >> 4;      // Cout is a multiple of 64
+    float4 ssum = make_float4(0.f, 0.f, 0.f, 0.f), ssq = ssum;
+    const float4 bs = bias ? *reinterpret_cast<const float4*>(bias + 4 * cq) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int p = p0 + pl + 16 * i;
+        if (p >= HW) break;
+        const size_t idx = ((size_t)b * HW + p) * Cout + 4 * cq;
+        float4 v = *reinterpret_cast<const float4*>(planes + idx);
+        for (int j = 1; j < ksplit; ++j) {
+            const float4 w = *reinterpret_cast<const float4*>(planes + (size_t)j * plane_elems + idx);
+            v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
         }
-        if (stats) {
-            red_s[tid] = ssum; red_q[tid] = ssq;
-            __syncthreads();
-            if (tid < span) {
-                float4 s4 = red_s[tid], q4 = red_q[tid];
-                for (int l = 1; l < npl; ++l) {
-                    const float4 a = red_s[l * span + tid], q = red_q[l * span + tid];
-                    s4.x += a.x; s4.y += a.y; s4.z += a.z; s4.w += a.w;
-                    q4.x += q.x; q4.y += q.y; q4.z += q.z; q4.w += q.w;
-                }
-                float* o = stats + (((size_t)b * nrec + blockIdx.x) * Cout + 4 * (cq0 + tid)) * 2;
-                *reinterpret_cast<float4*>(o) = make_float4(s4.x, q4.x, s4.y, q4.y);
-                *reinterpret_cast<float4*>(o + 4) = make_float4(s4.z, q4.z, s4.w, q4.w);
+        v.x += bs.x; v.y += bs.y; v.z += bs.z; v.w += bs.w;
+        if (res) {
+            const int y = p / W, x = p - y * W;
+            const size_t rp = res_up ? ((size_t)(b * (H >> 1) + (y >> 1)) * (W >> 1) + (x >> 1)) : ((size_t)b * HW + p);
+            const float4 r = *reinterpret_cast<const float4*>(res + rp * Cout + 4 * cq);
+            v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+        }
+        *reinterpret_cast<float4*>(out + idx) = v;
+        ssum.x += v.x; ssum.y += v.y; ssum.z += v.z; ssum.w += v.w;
+        ssq.x += v.x * v.x; ssq.y += v.y * v.y; ssq.z += v.z * v.z; ssq.w += v.w * v.w;
+    }
+    if (stats) {
+        red_s[tid] = ssum; red_q[tid] = ssq;
+        __syncthreads();
+        if (tid < 16) {
+            float4 s4 = red_s[tid], q4 = red_q[tid];
+            for (int l = 1; l < 16; ++l) {
+                const float4 a = red_s[l * 16 + tid], q = red_q[l * 16 + tid];
+                s4.x += a.x; s4.y += a.y; s4.z += a.z; s4.w += a.w;
+                q4.x += q.x; q4.y += q.y; q4.z += q.z; q4.w += q.w;
             }
-            __syncthreads();
+            float* o = stats + (((size_t)b * nrec + blockIdx.x) * Cout + 4 * cq) * 2;
+            *reinterpret_cast<float4*>(o) = make_float4(s4.x, q4.x, s4.y, q4.y);
+            *reinterpret_cast<float4*>(o + 4) = make_float4(s4.z, q4.z, s4.w, q4.w);
         }
     }
 }
 void launch_conv_reduce(const float* planes, int ksplit, const float* bias, const float* res, int res_up, float* out, float* stats,
                         int B, int H, int W, int Cout, hipStream_t stream) {
-    hipLaunchKernelGGL(conv_reduce_kernel, dim3((H * W + 63) / 64, B), dim3(256), 0, stream, planes, ksplit, bias, res, res_up, out,
+    hipLaunchKernelGGL(conv_reduce_kernel, dim3((H * W + 63) / 64, B, Cout / 64), dim3(256), 0, stream, planes, ksplit, bias, res, res_up, out,
                        stats, H, W, Cout, (size_t)B * H * W * Cout);
 }
 
