@@ -207,30 +207,57 @@ class DDPM_2D(_Base):
                 prm.data = self._trainer.p[k]
         return self._trainer
 
+    def hip_encoder_trainer(self, device):
+        """training state of the native context encoder (encoder_training.EncoderTrainer) when `self.encoder` is this package's ResNet-50
+        (plain or inside SparK_2D_encoder, whose timm model carries drop_path_rate 0.05: spark/models.py:89-109); None for any other
+        encoder module (it is then used as a frozen feature extractor). The module's parameters and BatchNorm buffers become views of the
+        trainer's tensors, as for the UNet."""
+        if getattr(self, "_enc_trainer", None) is None:
+            from .DDPM_encoder import ResNet50Encoder, SparK_2D_encoder
+            from .encoder_training import EncoderTrainer
+            enc = getattr(self, "encoder", None)
+            spark = isinstance(enc, SparK_2D_encoder)
+            core = enc.encoder if spark else enc
+            if not isinstance(core, ResNet50Encoder):
+                return None
+            sd = {k: v for k, v in core.state_dict().items() if not k.endswith("num_batches_tracked")}
+            self._enc_trainer = EncoderTrainer(sd, self.hip_trainer(device), drop_path_rate=0.05 if spark else 0.0)
+            full = self._enc_trainer.state_dict()
+            for k, prm in list(core.named_parameters()) + list(core.named_buffers()):
+                if k in full:
+                    prm.data = full[k]
+            self._enc_core = core
+        return self._enc_trainer
+
     def training_step(self, batch, batch_idx: int):
         """One optimisation step of the reference's training_step (:114-135): input = batch['vol'][DATA].squeeze(-1), context = encoder(input),
         noise = gen_noise(cfg) or Gaussian, loss = diffusion(input, cond, noise) at random t (cond_DDPM.py:647-655) -- with the gradient,
         the data-parallel all-reduce and Adam(lr = cfg.lr) (:305-306) done HERE on the HIP operators (training.training_step): this module
         runs under Lightning's manual optimisation (`automatic_optimization = False`), there is no autograd graph to hand back.
-        Deviation, stated: the context encoder is not updated (its backward is not built; `hip_trainer(...).dcond` holds dL/d(context)
-        for whoever trains it); the reference with pretrained_encoder=False trains it jointly."""
+        The native context encoder (this package's ResNet-50, plain or SparK-wrapped) is trained jointly, in training mode (BatchNorm batch
+        statistics, stochastic depth), as `optim.Adam(self.parameters())` does in the reference; any other `encoder=` module is used as a
+        frozen feature extractor (`hip_trainer(...).dcond` holds dL/d(context) for whoever trains it)."""
         from . import training as _training
         vol = batch["vol"]
         input = vol["data"].squeeze(-1).float()              # torchio's DATA key is the string "data"
         dev = input.device
-        features = self(input)
+        trainer = self.hip_trainer(dev)
+        enc_trainer = self.hip_encoder_trainer(dev) if _cfg_get(self.cfg, "condition", True) else None
+        features = None if enc_trainer is not None else self(input)        # the native encoder is run (in training mode) by the step itself
         noise = self._gen_noise(input.shape, dev)
         if noise is None:
             noise = torch.randn_like(input)
         d = self.diffusion
         t = torch.randint(0, d.num_timesteps, (input.shape[0],), device=dev).long()
-        trainer = self.hip_trainer(dev)
         ddp = torch.distributed.is_available() and torch.distributed.is_initialized()
-        loss = _training.training_step(trainer, input, features.float(), t=t, noise=noise.float(), timesteps=d.num_timesteps,
+        loss = _training.training_step(trainer, input, None if features is None else features.float(), t=t, noise=noise.float(),
+                                       timesteps=d.num_timesteps, encoder=enc_trainer,
                                        objective=d.objective, loss_type=d.loss_type, all_reduce=ddp, lr=_cfg_get(self.cfg, "lr", 1e-4),
                                        buffers={k: getattr(d, k) for k in ("sqrt_alphas_cumprod", "sqrt_one_minus_alphas_cumprod",
                                                                            "p2_loss_weight")})
         d.model._hip.invalidate()
+        if enc_trainer is not None:
+            self._enc_core._key = None                    # the inference encoder re-reads the updated weights and running statistics
         if hasattr(self, "log") and _Base is not nn.Module:
             try:
                 self.log(f"{self.prefix}train/Loss", loss, prog_bar=False, on_step=False, on_epoch=True, batch_size=input.shape[0], sync_dist=True)

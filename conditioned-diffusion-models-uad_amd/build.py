@@ -11,7 +11,7 @@ import sys
 from concurrent.futures import ThreadPoolExecutor
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-SOURCES = ["conv_mfma.hip", "conv_x6.hip", "norm_kernels.hip", "small_kernels.hip", "attention.hip", "simplex.hip", "encoder.hip", "eval_post.hip", "train_kernels.hip", "cddpm_api.hip"]
+SOURCES = ["conv_mfma.hip", "conv_x6.hip", "norm_kernels.hip", "small_kernels.hip", "attention.hip", "simplex.hip", "encoder.hip", "eval_post.hip", "train_kernels.hip", "encoder_train.hip", "cddpm_api.hip"]
 LIB = os.path.join(CSRC, "libcddpm_hip.so")
 OBJ = os.path.join(CSRC, "_obj")      # object files: git-ignored and .gpurunignore-d (only the .so travels to the GPU box)
 ARCH = "gfx950"

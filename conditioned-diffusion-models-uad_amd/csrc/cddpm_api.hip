@@ -1728,6 +1728,85 @@ int cddpm_op_adam(cddpm_handle h, float* p_dev, const float* g_dev, float* m_dev
     OP_EPILOGUE()
 }
 
+// ---- training-mode operators of the context encoder (encoder_train.hip): NHWC fp32 device tensors ---------------------------------------
+int cddpm_op_enc_pack_w(cddpm_handle h, const float* w_dev, int Cout, int Cin, int K, float* wf_dev, float* wd_dev, void* stream) {
+    OP_PROLOGUE(w_dev && wf_dev && Cout > 0 && Cin > 0 && (K == 1 || K == 3), "cddpm_op_enc_pack_w: bad arguments")
+    launch_enc_pack_w(w_dev, Cout, Cin, K * K, wf_dev, wd_dev, s);
+    OP_EPILOGUE()
+}
+int cddpm_op_enc_conv(cddpm_handle h, const float* src_dev, const float* w_img_dev, float* dst_dev, int B, int H, int W, int Cin, int Cout, int K,
+                      int stride, int transposed, void* stream) {
+    OP_PROLOGUE(src_dev && w_img_dev && dst_dev && B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && (K == 1 || K == 3) && (stride == 1 || stride == 2) &&
+                    (transposed ? (Cout % 16 == 0 && Cin % 64 == 0) : (Cin % 16 == 0 && Cout % 64 == 0)),
+                "cddpm_op_enc_conv: unsupported shape (contraction channels a multiple of 16, produced channels of 64; K 1|3, stride 1|2)")
+    launch_enc_conv(src_dev, w_img_dev, dst_dev, B, H, W, Cin, Cout, K, stride, transposed, s);
+    OP_EPILOGUE()
+}
+int cddpm_op_enc_conv_wgrad(cddpm_handle h, const float* x_dev, const float* dz_dev, float* dw_dev, int B, int H, int W, int Cin, int Cout, int K,
+                            int stride, void* stream) {
+    OP_PROLOGUE(x_dev && dz_dev && dw_dev && B > 0 && H > 0 && W > 0 && Cin > 0 && Cin % 64 == 0 && Cout > 0 && Cout % 64 == 0 && (K == 1 || K == 3) &&
+                    (stride == 1 || stride == 2), "cddpm_op_enc_conv_wgrad: unsupported shape")
+    const int Ho = (H + stride - 1) / stride, Wo = (W + stride - 1) / stride;
+    const int P = enc_wgrad_parts(B, Ho, Wo, Cin, Cout, K);
+    OpScratch sc(h, s);
+    float* part = sc.n<float>((size_t)P * K * K * Cin * Cout);
+    SCRATCH_CHECK(sc)
+    launch_enc_wgrad(x_dev, dz_dev, part, P, dw_dev, B, H, W, Cin, Cout, K, stride, s);
+    OP_EPILOGUE()
+}
+int cddpm_op_enc_stem(cddpm_handle h, const float* x_dev, const float* w_dev, float* z_dev, int B, int H, int W, void* stream) {
+    OP_PROLOGUE(x_dev && w_dev && z_dev && B > 0 && H > 0 && W > 0, "cddpm_op_enc_stem: bad arguments")
+    launch_enc_stem_fwd(x_dev, w_dev, z_dev, B, H, W, s);
+    OP_EPILOGUE()
+}
+int cddpm_op_enc_stem_wgrad(cddpm_handle h, const float* x_dev, const float* dz_dev, float* dw_dev, int B, int H, int W, void* stream) {
+    OP_PROLOGUE(x_dev && dz_dev && dw_dev && B > 0 && H > 0 && W > 0, "cddpm_op_enc_stem_wgrad: bad arguments")
+    OpScratch sc(h, s);
+    double* part = sc.n<double>((size_t)32 * 49 * 64);
+    SCRATCH_CHECK(sc)
+    launch_enc_stem_wgrad(x_dev, dz_dev, part, dw_dev, B, H, W, s);
+    OP_EPILOGUE()
+}
+int cddpm_op_enc_bn_forward(cddpm_handle h, const float* z_dev, const float* gamma_dev, const float* beta_dev, const float* sample_scale_dev,
+                            const float* res_dev, int relu, float eps, float momentum, float* run_mean_dev, float* run_var_dev, float* mean_rstd_dev,
+                            float* y_dev, int64_t N, int HW, int C, void* stream) {
+    OP_PROLOGUE(z_dev && gamma_dev && beta_dev && mean_rstd_dev && y_dev && N > 0 && HW > 0 && C > 0 && C % 64 == 0 && (!run_mean_dev == !run_var_dev),
+                "cddpm_op_enc_bn_forward: bad arguments (C a multiple of 64)")
+    OpScratch sc(h, s);
+    double* part = sc.n<double>((size_t)enc_bn_chunks(N) * 2 * C);
+    SCRATCH_CHECK(sc)
+    launch_enc_bn_forward(z_dev, gamma_dev, beta_dev, sample_scale_dev, res_dev, relu, eps, momentum, run_mean_dev, run_var_dev, mean_rstd_dev, y_dev,
+                          part, N, HW, C, s);
+    OP_EPILOGUE()
+}
+int cddpm_op_enc_bn_backward(cddpm_handle h, const float* z_dev, const float* y_dev, const float* dy_dev, const float* mean_rstd_dev,
+                             const float* gamma_dev, const float* sample_scale_dev, int relu, float* dz_dev, float* dres_dev, float* dgamma_dev,
+                             float* dbeta_dev, int64_t N, int HW, int C, void* stream) {
+    OP_PROLOGUE(z_dev && dy_dev && mean_rstd_dev && gamma_dev && dz_dev && dgamma_dev && dbeta_dev && (!relu || y_dev) && N > 0 && HW > 0 && C > 0 &&
+                    C % 64 == 0, "cddpm_op_enc_bn_backward: bad arguments (C a multiple of 64)")
+    OpScratch sc(h, s);
+    double* part = sc.n<double>((size_t)enc_bn_chunks(N) * 2 * C);
+    float* k = sc.n<float>((size_t)2 * C);
+    SCRATCH_CHECK(sc)
+    launch_enc_bn_backward(z_dev, y_dev, dy_dev, mean_rstd_dev, gamma_dev, sample_scale_dev, relu, dz_dev, dres_dev, dgamma_dev, dbeta_dev, k, part, N,
+                           HW, C, s);
+    OP_EPILOGUE()
+}
+int cddpm_op_enc_maxpool(cddpm_handle h, const float* x_dev, float* y_dev, int B, int H, int W, int C, int backward, const float* dy_dev, float* dx_dev,
+                         void* stream) {
+    OP_PROLOGUE(x_dev && B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && (backward ? (dy_dev && dx_dev) : (y_dev != nullptr)),
+                "cddpm_op_enc_maxpool: bad arguments")
+    if (backward) launch_enc_maxpool_backward(x_dev, dy_dev, dx_dev, B, H, W, C, s);
+    else launch_enc_maxpool(x_dev, y_dev, B, H, W, C, s);
+    OP_EPILOGUE()
+}
+int cddpm_op_enc_avgpool(cddpm_handle h, const float* x_dev, float* g_dev, int B, int HW, int C, int backward, void* stream) {
+    OP_PROLOGUE(x_dev && g_dev && B > 0 && HW > 0 && C > 0, "cddpm_op_enc_avgpool: bad arguments")
+    if (backward) launch_enc_avgpool_backward(x_dev /* dL/dg [B][C] */, g_dev /* dL/dx [B][HW][C] */, B, HW, C, s);
+    else launch_enc_avgpool(x_dev, g_dev, B, HW, C, s);
+    OP_EPILOGUE()
+}
+
 int cddpm_op_gn_silu_backward(cddpm_handle h, const float* x_dev, const float* da_dev, const float* gamma_host,
                               const float* beta_host, const float* film_dev, int silu, float* dx_dev, float* dgamma_dev,
                               float* dbeta_dev, float* dfilm_dev, int B, int HW, int C, void* stream) {

@@ -195,4 +195,25 @@ void launch_residual_mask(const float* orig, const float* recon, const float* ma
                           int squared, int iters, hipStream_t stream);
 void launch_median3d(const float* in, float* out, int S, int H, int W, int k, hipStream_t stream);
 
+// ---- training-mode kernels of the context encoder (encoder_train.hip)
+void launch_enc_conv(const float* src, const float* w_img, float* dst, int B, int H, int W, int Cin, int Cout, int K, int stride, int transposed,
+                     hipStream_t s);
+void launch_enc_pack_w(const float* w, int Cout, int Cin, int taps, float* wf, float* wd, hipStream_t s);
+int enc_wgrad_parts(int B, int Ho, int Wo, int Cin, int Cout, int K);
+void launch_enc_wgrad(const float* x, const float* dz, float* part, int P, float* dw, int B, int H, int W, int Cin, int Cout, int K, int stride,
+                      hipStream_t s);
+void launch_enc_stem_fwd(const float* x, const float* w, float* z, int B, int H, int W, hipStream_t s);
+void launch_enc_stem_wgrad(const float* x, const float* dz, double* part /* 32 * 49 * 64 */, float* dw, int B, int H, int W, hipStream_t s);
+int enc_bn_chunks(long long N);
+void launch_enc_bn_forward(const float* z, const float* gamma, const float* beta, const float* sscale, const float* res, int relu, float eps,
+                           float momentum, float* run_mean, float* run_var, float* mr, float* y, double* part, long long N, int HW, int C,
+                           hipStream_t s);
+void launch_enc_bn_backward(const float* z, const float* y, const float* dy, const float* mr, const float* gamma, const float* sscale, int relu,
+                            float* dz, float* dres, float* dgamma, float* dbeta, float* k, double* part, long long N, int HW, int C,
+                            hipStream_t s);
+void launch_enc_maxpool(const float* x, float* y, int B, int H, int W, int C, hipStream_t s);
+void launch_enc_maxpool_backward(const float* x, const float* dy, float* dx, int B, int H, int W, int C, hipStream_t s);
+void launch_enc_avgpool(const float* x, float* g, int B, int HW, int C, hipStream_t s);
+void launch_enc_avgpool_backward(const float* dg, float* dx, int B, int HW, int C, hipStream_t s);
+
 }  // namespace cddpm

@@ -466,14 +466,20 @@ def all_reduce_sum_(flat: torch.Tensor) -> int:
     return 1
 
 
-def training_step(trainer: UNetTrainer, x01: torch.Tensor, cond: torch.Tensor, *, t: torch.Tensor, noise: torch.Tensor, timesteps=1000,
-                  objective="pred_x0", loss_type="l1", all_reduce=False, lr=1e-4, buffers=None):
+def training_step(trainer: UNetTrainer, x01: torch.Tensor, cond: Optional[torch.Tensor], *, t: torch.Tensor, noise: torch.Tensor, timesteps=1000,
+                  objective="pred_x0", loss_type="l1", all_reduce=False, lr=1e-4, buffers=None, encoder=None):
     """One optimisation step of the diffusion loss (cond_DDPM.py:647-655 -> :565-645; DDPM_2D.py:114-135): x01 [B,1,H,W] in [0,1], context
     cond [B,cond_dim], per-sample timesteps t and noise given by the caller; `buffers`: the diffusion's schedule tables (default: the
     cosine schedule of `timesteps`). Returns the loss. `all_reduce`: sum the gradients over the ranks of torch.distributed (RCCL) before
-    the update -- the data-parallel training of the reference (Lightning DDP, src/train.py:62-65)."""
+    the update -- the data-parallel training of the reference (Lightning DDP, src/train.py:62-65).
+    `encoder` (an encoder_training.EncoderTrainer): the context is computed by it in training mode (cond is ignored) and it is trained
+    jointly -- dL/d(context) of the UNet's backward flows into its backward, its gradients join the all-reduce and its own Adam step runs
+    with the same learning rate: `features = self(input)` + `optim.Adam(self.parameters())` of the reference."""
     buf = buffers if buffers is not None else _schedule.schedule_buffers(timesteps)
     dev = trainer.dev
+    trainer._fit(*[x01.shape[i] for i in (0, 2, 3)])       # the handle and its scratch arena before the first operator runs
+    if encoder is not None:
+        cond = encoder.forward(x01)
     x0 = x01.float() * 2 - 1
     sa = buf["sqrt_alphas_cumprod"].to(dev)[t].reshape(-1, 1, 1, 1)
     s1 = buf["sqrt_one_minus_alphas_cumprod"].to(dev)[t].reshape(-1, 1, 1, 1)
@@ -483,6 +489,12 @@ def training_step(trainer: UNetTrainer, x01: torch.Tensor, cond: torch.Tensor, *
     p2w = buf["p2_loss_weight"].to(dev)[t].contiguous()
     loss, dout = trainer.loss_and_grad(out, target, p2w, loss_type)
     trainer.backward(dout)
+    if encoder is not None:
+        encoder.backward(trainer.dcond)                    # carries the same loss scale
     world = all_reduce_sum_(trainer.gflat) if all_reduce else 1
+    if encoder is not None and all_reduce:
+        all_reduce_sum_(encoder.gflat)
     trainer.adam_step(lr=lr, grad_scale=trainer.grad_scale * world)        # the mean over ranks folds into Adam's unscale factor
+    if encoder is not None:
+        encoder.adam_step(lr=lr, grad_scale=trainer.grad_scale * world)
     return loss

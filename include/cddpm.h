@@ -323,6 +323,39 @@ int cddpm_op_conv_packed(cddpm_handle h, const float* src0_dev, int C0, const fl
                          int folded_up, const void* packed_dev, int scale_exp, const float* bias_dev, int Cout, int ksize,
                          const float* res_dev, int res_upsample, const float* skip_dev, int S0, const void* skip_packed_dev,
                          float* out_dev, int B, int H, int W, void* stream);
+/* ---- training-mode operators of the context encoder (timm ResNet-50, in_chans = 1; reference src/models/modules/DDPM_encoder.py:21-23,
+ * trained jointly with the UNet by src/models/DDPM_2D.py:114-135 / :305-306). NHWC fp32 device tensors, plain fp32 FMA kernels (the encoder is
+ * ~5 % of a training step's FLOPs). Strided operators map n -> ceil(n / stride).
+ * cddpm_op_enc_pack_w: PyTorch weight [Cout][Cin][K][K] -> the images the convolution reads: wf [K*K][Cin][Cout] (forward) and, when wd_dev is
+ *   given, wd [K*K][Cout][Cin] (input gradient).
+ * cddpm_op_enc_conv: transposed = 0: z [B,Ho,Wo,Cout] = conv_K,stride,pad K/2 (x [B,H,W,Cin]) with wf; transposed = 1: dx [B,H,W,Cin] from
+ *   dz [B,Ho,Wo,Cout] with wd (H, W are always the convolution's INPUT size). No bias (ResNet convolutions have none).
+ * cddpm_op_enc_conv_wgrad: dw [Cout][Cin][K][K] (PyTorch layout) from x and dz.  cddpm_op_enc_stem / _stem_wgrad: the 7x7 / 2 single-channel stem
+ *   (x [B,H,W] -> z [B,ceil(H/2),ceil(W/2),64], weight [64][49]).
+ * cddpm_op_enc_bn_forward: BatchNorm2d in TRAINING mode + optional shortcut + optional ReLU:
+ *   y = relu(((z - mean_c) rstd_c gamma_c + beta_c) s_b + res), batch statistics over the N = B * HW pixels (fp64 sums), mean_rstd_dev [2][C] kept
+ *   for the backward, running statistics updated as torch does (momentum, unbiased variance) when given; s_b (sample_scale_dev [B] or NULL = 1) is
+ *   the stochastic-depth scale of the residual branch (timm drop_path).  cddpm_op_enc_bn_backward: dz, dgamma, dbeta and (dres_dev given) the
+ *   shortcut operand's gradient dy [y > 0].
+ * cddpm_op_enc_maxpool: 3x3 / 2 pad 1 forward (backward = 0) or its backward in gather form (first maximum in row-major order, as torch;
+ *   deterministic).  cddpm_op_enc_avgpool: global average pool x [B,HW,C] -> g [B,C], or (backward = 1) dL/dg [B,C] (first pointer) -> dL/dx (second). */
+int cddpm_op_enc_pack_w(cddpm_handle h, const float* w_dev, int Cout, int Cin, int K, float* wf_dev, float* wd_dev, void* stream);
+int cddpm_op_enc_conv(cddpm_handle h, const float* src_dev, const float* w_img_dev, float* dst_dev, int B, int H, int W, int Cin, int Cout, int K,
+                      int stride, int transposed, void* stream);
+int cddpm_op_enc_conv_wgrad(cddpm_handle h, const float* x_dev, const float* dz_dev, float* dw_dev, int B, int H, int W, int Cin, int Cout, int K,
+                            int stride, void* stream);
+int cddpm_op_enc_stem(cddpm_handle h, const float* x_dev, const float* w_dev, float* z_dev, int B, int H, int W, void* stream);
+int cddpm_op_enc_stem_wgrad(cddpm_handle h, const float* x_dev, const float* dz_dev, float* dw_dev, int B, int H, int W, void* stream);
+int cddpm_op_enc_bn_forward(cddpm_handle h, const float* z_dev, const float* gamma_dev, const float* beta_dev, const float* sample_scale_dev,
+                            const float* res_dev, int relu, float eps, float momentum, float* run_mean_dev, float* run_var_dev, float* mean_rstd_dev,
+                            float* y_dev, int64_t N, int HW, int C, void* stream);
+int cddpm_op_enc_bn_backward(cddpm_handle h, const float* z_dev, const float* y_dev, const float* dy_dev, const float* mean_rstd_dev,
+                             const float* gamma_dev, const float* sample_scale_dev, int relu, float* dz_dev, float* dres_dev, float* dgamma_dev,
+                             float* dbeta_dev, int64_t N, int HW, int C, void* stream);
+int cddpm_op_enc_maxpool(cddpm_handle h, const float* x_dev, float* y_dev, int B, int H, int W, int C, int backward, const float* dy_dev, float* dx_dev,
+                         void* stream);
+int cddpm_op_enc_avgpool(cddpm_handle h, const float* x_dev, float* g_dev, int B, int HW, int C, int backward, void* stream);
+
 /* backward of a = act(GroupNorm32(x) * (1 + scale) + shift), act = SiLU (silu != 0) or identity (OpenAI_Unet.py:284-338, :325-330):
  * given da_dev [B,HW,C] writes dx_dev [B,HW,C], dgamma_dev / dbeta_dev [C] and, when film_dev ([B][2C] scale | shift) is given,
  * dfilm_dev [B][2C]. The forward statistics are recomputed from x_dev. Everything NHWC fp32. */

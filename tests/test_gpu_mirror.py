@@ -208,3 +208,31 @@ def test_ddpm2d_training_step_updates_the_unet(sd_np, synth):
     loss1, reco1 = mod.reconstruct(inp, noise=probe_noise)
     assert float((reco1 - reco0).abs().max()) > 1e-4                           # ... and evaluation runs on the updated weights
     print("training losses", losses, "probe", float(loss0), "->", float(loss1))
+
+
+def test_ddpm2d_training_step_trains_the_native_encoder_jointly(sd_np, synth):
+    """with this package's own context encoder (the ResNet-50 behind get_encoder) the training step runs it in training mode and updates
+    it together with the UNet (`features = self(input)` with a gradient + `Adam(self.parameters())`, reference src/models/DDPM_2D.py:114-135,
+    :305-306): encoder weights and BatchNorm running statistics move, state_dict() sees them, evaluation re-reads them"""
+    M, E = load_pkg("DDPM_2D"), load_pkg("DDPM_encoder")
+    cfg = dict(imageDim=[128, 128, 100], rescaleFactor=2, unet_dim=128, dim_mults=[1, 2, 2], condition=True, test_timesteps=500, timesteps=1000,
+               lr=1e-4, backbone="resnet50", cond_dim=128)
+    enc = E.ResNet50Encoder(num_classes=128, in_chans=1)
+    enc.load_state_dict({k: torch.from_numpy(v) for k, v in synth.synth_encoder_state_dict(0).items()}, strict=False)
+    mod = M.DDPM_2D(cfg, encoder=enc)
+    mod.diffusion.model.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()})
+    mod = mod.cuda()
+    vol = torch.from_numpy(synth.synth_slices(4, 0, 4, 64, 64)).reshape(4, 1, 64, 64, 1).cuda()
+    inp = vol.squeeze(-1)
+    c0 = mod(inp).clone()
+    w0 = mod.encoder.state_dict()["layer3.2.conv2.weight"].clone()
+    rm0 = mod.encoder.state_dict()["layer1.0.bn1.running_mean"].clone()
+    torch.manual_seed(1)
+    losses = [float(mod.training_step({"vol": {"data": vol}}, i)["loss"]) for i in range(3)]
+    assert all(np.isfinite(losses))
+    sd = mod.encoder.state_dict()
+    assert float((sd["layer3.2.conv2.weight"] - w0).abs().max()) > 1e-5
+    assert float((sd["layer1.0.bn1.running_mean"] - rm0).abs().max()) > 1e-6
+    c1 = mod(inp)
+    assert torch.isfinite(c1).all() and float((c1 - c0).abs().max()) > 1e-4
+    print("joint training losses", losses)

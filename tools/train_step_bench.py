@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--size", type=int, default=128)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--encoder", action="store_true", help="train the context encoder (ResNet-50) jointly, as the reference does")
     ap.add_argument("--phases", action="store_true", help="time forward / backward / adam separately (synchronises between them)")
     a = ap.parse_args()
     tr = importlib.import_module(PKG + ".training")
@@ -35,6 +36,10 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
     sd = synth.synth_state_dict(0)
     trainer = tr.UNetTrainer({k: torch.from_numpy(v) for k, v in sd.items()}, device=dev)
+    enc = None
+    if a.encoder:
+        et = importlib.import_module(PKG + ".encoder_training")
+        enc = et.EncoderTrainer({k: torch.from_numpy(v) for k, v in synth.synth_encoder_state_dict(0).items()}, trainer, drop_path_rate=0.05)
     B, S, T = a.batch, a.size, 1000
     x01 = torch.from_numpy(synth.synth_slices(1, rank * B, B, S, S)).reshape(B, 1, S, S).to(dev)      # each rank its own slices
     cond = torch.from_numpy(synth.synth_cond(1, rank * B, B)).to(dev)
@@ -42,13 +47,13 @@ def main():
     t = torch.tensor([(137 * (i + 1)) % T for i in range(B)], dtype=torch.long, device=dev)
     losses = []
     for _ in range(a.warmup):
-        losses.append(float(tr.training_step(trainer, x01, cond, t=t, noise=noise, objective="pred_noise", loss_type="l2", all_reduce=ddp)))
+        losses.append(float(tr.training_step(trainer, x01, cond, t=t, noise=noise, objective="pred_noise", loss_type="l2", all_reduce=ddp, encoder=enc)))
     torch.cuda.synchronize()
     if ddp:
         dist.barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        loss = tr.training_step(trainer, x01, cond, t=t, noise=noise, objective="pred_noise", loss_type="l2", all_reduce=ddp)
+        loss = tr.training_step(trainer, x01, cond, t=t, noise=noise, objective="pred_noise", loss_type="l2", all_reduce=ddp, encoder=enc)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / a.steps
     if ddp:
@@ -56,7 +61,7 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax)
     losses.append(float(loss))
-    res = {"workload": f"training step {B}x1x{S}x{S} (noise-pred MSE, fp32-emulated convolutions, Adam)", "ms_per_step": dt * 1e3,
+    res = {"workload": f"training step {B}x1x{S}x{S} (noise-pred MSE, fp32-emulated convolutions, Adam" + (", context encoder trained jointly)" if enc else ")"), "ms_per_step": dt * 1e3,
            "slices_per_s": world * B / dt, "n_gpus": world, "losses": losses, "peak_mem_GB": torch.cuda.max_memory_allocated() / 2 ** 30}
     if a.phases:
         buf = importlib.import_module(PKG + ".schedule").schedule_buffers(T)
