@@ -1739,7 +1739,15 @@ int cddpm_op_enc_conv(cddpm_handle h, const float* src_dev, const float* w_img_d
     OP_PROLOGUE(src_dev && w_img_dev && dst_dev && B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && (K == 1 || K == 3) && (stride == 1 || stride == 2) &&
                     (transposed ? (Cout % 16 == 0 && Cin % 64 == 0) : (Cin % 16 == 0 && Cout % 64 == 0)),
                 "cddpm_op_enc_conv: unsupported shape (contraction channels a multiple of 16, produced channels of 64; K 1|3, stride 1|2)")
-    launch_enc_conv(src_dev, w_img_dev, dst_dev, B, H, W, Cin, Cout, K, stride, transposed, s);
+    const int Z = enc_conv_split(B, H, W, Cin, Cout, K, stride, transposed);
+    OpScratch sc(h, s);
+    float* part = nullptr;
+    if (Z > 1) {
+        const int Ho = (H + stride - 1) / stride, Wo = (W + stride - 1) / stride;
+        part = sc.n<float>((size_t)Z * B * (transposed ? (size_t)H * W * Cin : (size_t)Ho * Wo * Cout));
+        SCRATCH_CHECK(sc)
+    }
+    launch_enc_conv(src_dev, w_img_dev, dst_dev, B, H, W, Cin, Cout, K, stride, transposed, part, s);
     OP_EPILOGUE()
 }
 int cddpm_op_enc_conv_wgrad(cddpm_handle h, const float* x_dev, const float* dz_dev, float* dw_dev, int B, int H, int W, int Cin, int Cout, int K,

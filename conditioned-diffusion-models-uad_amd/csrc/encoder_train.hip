@@ -27,6 +27,8 @@ struct EncGemmConv {
     float* dst;            // forward: z [B,Ho,Wo,Ndim]; input gradient: dx [B,H,W,Ndim]
     int B, H, W, Ho, Wo;   // H, W: the convolution's input size; Ho, Wo: its output size
     int Kdim, Ndim, K, stride, transposed;
+    int Z;                 // contraction split: blockIdx.z multiplies steps [nstep z / Z, nstep (z + 1) / Z) into plane z of `part`
+    float* part;           // [Z][rows][Ndim] when Z > 1 (folded in the order of z by enc_fold_planes_kernel)
 };
 __global__ __launch_bounds__(256) void enc_gemm_conv_kernel(const EncGemmConv a) {
     __shared__ float As[16][64 + 4];
@@ -50,7 +52,10 @@ __global__ __launch_bounds__(256) void enc_gemm_conv_kernel(const EncGemmConv a)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
     const int pad = a.K / 2, taps = a.K * a.K;
-    for (int t = 0; t < taps; ++t) {
+    const int nck = a.Kdim / 16, nstep = taps * nck;
+    // one step = 16 contraction channels of one tap; the next step's two global loads are in flight while this step multiplies
+    auto fetch = [&](int step, float4& av, float4& bv) {
+        const int t = step / nck, c0 = (step - t * nck) * 16;
         const int ky = t / a.K, kx = t - ky * a.K;
         int ys, xs;
         bool inb = lvalid;
@@ -61,42 +66,71 @@ __global__ __launch_bounds__(256) void enc_gemm_conv_kernel(const EncGemmConv a)
             ys = ny / a.stride; xs = nx / a.stride;
         }
         inb = inb && ys >= 0 && ys < Hs && xs >= 0 && xs < Ws;
-        const float* xp = a.src + (((size_t)lb * Hs + (inb ? ys : 0)) * Ws + (inb ? xs : 0)) * a.Kdim;
-        const float* wp = a.w + (size_t)t * a.Kdim * a.Ndim;
-        for (int c0 = 0; c0 < a.Kdim; c0 += 16) {
-            float4 av = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (inb) av = *reinterpret_cast<const float4*>(xp + c0 + 4 * lc4);
-            const float4 bv = *reinterpret_cast<const float4*>(wp + (size_t)(c0 + bk) * a.Ndim + n0 + 4 * bc4);
-            __syncthreads();
-            As[4 * lc4 + 0][lp] = av.x; As[4 * lc4 + 1][lp] = av.y; As[4 * lc4 + 2][lp] = av.z; As[4 * lc4 + 3][lp] = av.w;
-            *reinterpret_cast<float4*>(&Bs[bk][4 * bc4]) = bv;
-            __syncthreads();
+        av = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (inb) av = *reinterpret_cast<const float4*>(a.src + (((size_t)lb * Hs + ys) * Ws + xs) * a.Kdim + c0 + 4 * lc4);
+        bv = *reinterpret_cast<const float4*>(a.w + ((size_t)t * a.Kdim + c0 + bk) * a.Ndim + n0 + 4 * bc4);
+    };
+    const int s0 = (int)((long long)nstep * blockIdx.z / a.Z), s1 = (int)((long long)nstep * (blockIdx.z + 1) / a.Z);
+    float4 av, bv;
+    fetch(s0, av, bv);
+    for (int step = s0; step < s1; ++step) {
+        __syncthreads();
+        As[4 * lc4 + 0][lp] = av.x; As[4 * lc4 + 1][lp] = av.y; As[4 * lc4 + 2][lp] = av.z; As[4 * lc4 + 3][lp] = av.w;
+        *reinterpret_cast<float4*>(&Bs[bk][4 * bc4]) = bv;
+        __syncthreads();
+        if (step + 1 < s1) fetch(step + 1, av, bv);
 #pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const float4 a4 = *reinterpret_cast<const float4*>(&As[k][4 * ty]);
-                const float4 b4 = *reinterpret_cast<const float4*>(&Bs[k][4 * tx]);
-                const float aa[4] = {a4.x, a4.y, a4.z, a4.w}, bb[4] = {b4.x, b4.y, b4.z, b4.w};
+        for (int k = 0; k < 16; ++k) {
+            const float4 a4 = *reinterpret_cast<const float4*>(&As[k][4 * ty]);
+            const float4 b4 = *reinterpret_cast<const float4*>(&Bs[k][4 * tx]);
+            const float aa[4] = {a4.x, a4.y, a4.z, a4.w}, bb[4] = {b4.x, b4.y, b4.z, b4.w};
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(aa[i], bb[j], acc[i][j]);
-            }
+                for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(aa[i], bb[j], acc[i][j]);
         }
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const long long p = p0 + 4 * ty + i;
         if (p >= M) continue;
-        *reinterpret_cast<float4*>(a.dst + (size_t)p * a.Ndim + n0 + 4 * tx) = make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]);
+        float* o = a.Z > 1 ? a.part + (size_t)blockIdx.z * M * a.Ndim : a.dst;
+        *reinterpret_cast<float4*>(o + (size_t)p * a.Ndim + n0 + 4 * tx) = make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]);
     }
 }
+__global__ __launch_bounds__(256) void enc_fold_planes_kernel(const float* __restrict__ part, int Z, long long n4, float* __restrict__ dst) {
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n4) return;
+    float4 s = reinterpret_cast<const float4*>(part)[e];
+    for (int z = 1; z < Z; ++z) {
+        const float4 v = reinterpret_cast<const float4*>(part)[(size_t)z * n4 + e];
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    reinterpret_cast<float4*>(dst)[e] = s;
+}
+// layers that give the chip fewer than 128 workgroups (the 8 x 8 and 4 x 4 stages at batch 16) split their contraction
+int enc_conv_split(int B, int H, int W, int Cin, int Cout, int K, int stride, int transposed) {
+    const int Ho = (H + stride - 1) / stride, Wo = (W + stride - 1) / stride;
+    const long long M = (long long)B * (transposed ? H * W : Ho * Wo);
+    const long long wgs = ((M + 63) / 64) * ((transposed ? Cin : Cout) / 64);
+    const int nstep = K * K * (transposed ? Cout : Cin) / 16;
+    int Z = 1;
+    while (Z < 8 && wgs * Z * 2 <= 256 && nstep / (Z * 2) >= 8) Z *= 2;
+    return Z;
+}
 void launch_enc_conv(const float* src, const float* w, float* dst, int B, int H, int W, int Cin, int Cout, int K, int stride, int transposed,
-                     hipStream_t s) {
+                     float* part, hipStream_t s) {
     EncGemmConv a;
+    a.Z = part ? enc_conv_split(B, H, W, Cin, Cout, K, stride, transposed) : 1;
+    a.part = part;
     a.src = src; a.w = w; a.dst = dst; a.B = B; a.H = H; a.W = W; a.Ho = (H + stride - 1) / stride; a.Wo = (W + stride - 1) / stride;
     a.Kdim = transposed ? Cout : Cin; a.Ndim = transposed ? Cin : Cout; a.K = K; a.stride = stride; a.transposed = transposed;
     const long long M = (long long)B * (transposed ? H * W : a.Ho * a.Wo);
-    hipLaunchKernelGGL(enc_gemm_conv_kernel, dim3((unsigned)((M + 63) / 64), (unsigned)(a.Ndim / 64)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(enc_gemm_conv_kernel, dim3((unsigned)((M + 63) / 64), (unsigned)(a.Ndim / 64), a.Z), dim3(256), 0, s, a);
+    if (a.Z > 1) {
+        const long long n4 = M * a.Ndim / 4;
+        hipLaunchKernelGGL(enc_fold_planes_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, part, a.Z, n4, dst);
+    }
 }
 
 // weight images of one convolution from the PyTorch tensor w [Cout][Cin][K][K]: wf [taps][Cin][Cout] (forward), wd [taps][Cout][Cin]
@@ -179,7 +213,7 @@ int enc_wgrad_parts(int B, int Ho, int Wo, int Cin, int Cout, int K) {
     const int per = (Cin / 64) * (Cout / 64) * K * K;
     long long P = (1024 + per - 1) / per;
     if (P > M / 64) P = M / 64;
-    if (P > 64) P = 64;
+    if (P > 16) P = 16;
     return P < 1 ? 1 : (int)P;
 }
 void launch_enc_wgrad(const float* x, const float* dz, float* part, int P, float* dw, int B, int H, int W, int Cin, int Cout, int K, int stride,
@@ -385,8 +419,8 @@ __global__ __launch_bounds__(256) void enc_bn_bwd_apply_kernel(const float* __re
     *reinterpret_cast<float4*>(dz + (size_t)p * C + c) = o;
 }
 int enc_bn_chunks(long long N) {
-    long long n = N / 64;
-    if (n > 128) n = 128;
+    long long n = N / 256;            // >= 16 pixels per pixel lane of a chunk; the folds read the chunks serially
+    if (n > 32) n = 32;
     return n < 1 ? 1 : (int)n;
 }
 void launch_enc_bn_forward(const float* z, const float* gamma, const float* beta, const float* sscale, const float* res, int relu, float eps,

@@ -196,8 +196,9 @@ void launch_residual_mask(const float* orig, const float* recon, const float* ma
 void launch_median3d(const float* in, float* out, int S, int H, int W, int k, hipStream_t stream);
 
 // ---- training-mode kernels of the context encoder (encoder_train.hip)
+int enc_conv_split(int B, int H, int W, int Cin, int Cout, int K, int stride, int transposed);     // planes of `part` (1: not used)
 void launch_enc_conv(const float* src, const float* w_img, float* dst, int B, int H, int W, int Cin, int Cout, int K, int stride, int transposed,
-                     hipStream_t s);
+                     float* part /* enc_conv_split() x rows x produced channels floats, or nullptr */, hipStream_t s);
 void launch_enc_pack_w(const float* w, int Cout, int Cin, int taps, float* wf, float* wd, hipStream_t s);
 int enc_wgrad_parts(int B, int Ho, int Wo, int Cin, int Cout, int K);
 void launch_enc_wgrad(const float* x, const float* dz, float* part, int P, float* dw, int B, int H, int W, int Cin, int Cout, int K, int stride,
