@@ -34,6 +34,8 @@ Extra objects on the JSON line:
                 v_mfma_f32_32x32x2_f32 -- the arithmetic `north_star` names) and CDDPM_CONV=x6 (exact 3-term bf16 split),
                 each in a child process (the family is chosen once per process).
   config.small_batch the reference's real call shape (DDPM_2D.py:193: 4 slices per volume): B = 4, 50 reverse steps.
+  config.training_step  BASELINE config 5's per-GPU share (16 x 1 x 128 x 128, noise-prediction MSE, Adam; the context encoder trained jointly,
+                as the reference does): ms per optimisation step on the HIP operators (training.py), 1 warm-up + 3 timed steps.
 """
 from __future__ import annotations
 
@@ -132,6 +134,28 @@ def run_chain(eng, synth, x, n_rev, slice0):
         eng.reverse_range_(x, T_TOTAL - 1, T_TOTAL - n, seed=3, slice0=slice0)
         done += n
     return x
+
+
+def training_rate(torch, dev, synth, B=16, S=128, steps=3):
+    """one optimisation step (training.training_step: q_sample, UNet forward / backward, encoder forward / backward, Adam) on B x 1 x S x S"""
+    tr, et = importlib.import_module(PKG + ".training"), importlib.import_module(PKG + ".encoder_training")
+    trainer = tr.UNetTrainer({k: torch.from_numpy(v) for k, v in synth.synth_state_dict(0).items()}, device=dev)
+    enc = et.EncoderTrainer({k: torch.from_numpy(v) for k, v in synth.synth_encoder_state_dict(0).items()}, trainer, drop_path_rate=0.05)
+    x01 = torch.from_numpy(synth.synth_slices(1, 0, B, S, S)).reshape(B, 1, S, S).to(dev)
+    noise = torch.from_numpy(synth.noise_xT(1, 0, B, S, S)).reshape(B, 1, S, S).to(dev)
+    t = torch.tensor([(137 * (i + 1)) % 1000 for i in range(B)], dtype=torch.long, device=dev)
+    kw = dict(t=t, noise=noise, objective="pred_noise", loss_type="l2", encoder=enc)
+    losses = [float(tr.training_step(trainer, x01, None, **kw))]
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = tr.training_step(trainer, x01, None, **kw)
+    torch.cuda.synchronize(dev)
+    dt = (time.perf_counter() - t0) / steps
+    losses.append(float(loss))
+    trainer.eng.close()
+    return {"workload": f"{B}x1x{S}x{S}, noise-pred MSE, Adam, UNet + context encoder", "ms_per_step": dt * 1e3, "slices_per_s": B / dt,
+            "dtype": "f32_emulated_f16x3 (convolutions), f32 elsewhere", "losses_first_last": losses}
 
 
 def short_rate(torch, dev, B, S, n_rev, warm):
@@ -322,6 +346,10 @@ def main():
             except Exception as e:      # the headline does not depend on the side measurements
                 alts[fam] = {"error": repr(e)}
         out["config"]["alt_paths"] = alts
+        try:
+            out["config"]["training_step"] = training_rate(torch, dev, synth)
+        except Exception as e:
+            out["config"]["training_step"] = {"error": repr(e)}
     if rank == 0 and world == 1 and not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(synth, S)
         out["config"]["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]

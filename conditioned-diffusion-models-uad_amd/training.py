@@ -28,6 +28,59 @@ def _p(t: Optional[torch.Tensor]):
     return None if t is None else t.data_ptr()
 
 
+def unet_program(model_channels=128, channel_mult=(1, 2, 2), num_res_blocks=3):
+    """the UNet as a list of (kind, state_dict prefix, attributes) in forward order -- UNetModel.__init__ / forward of the reference
+    (OpenAI_Unet.py:604-797, :823-1006) for the cDDPM configuration (resblock_updown, attention in the middle block only): the input
+    convolution, ResBlocks ('plain' | 'down' | 'up'; `push`: the output also goes on the skip stack; `concat`: channels popped from it
+    and concatenated to the input), the middle attention block, the output head."""
+    C_, prog, chans = model_channels, [], []
+    ch, idx = C_, 1
+    prog.append(("in", "input_blocks.0.0", None))
+    chans.append(C_)
+    for level, m in enumerate(channel_mult):
+        co = m * C_
+        for _ in range(num_res_blocks):
+            prog.append(("res", f"input_blocks.{idx}.0", dict(cin=ch, cout=co, kind="plain", push=True)))
+            ch = co
+            chans.append(ch)
+            idx += 1
+        if level != len(channel_mult) - 1:
+            prog.append(("res", f"input_blocks.{idx}.0", dict(cin=ch, cout=ch, kind="down", push=True)))
+            chans.append(ch)
+            idx += 1
+    prog.append(("res", "middle_block.0", dict(cin=ch, cout=ch, kind="plain")))
+    prog.append(("attn", "middle_block.1", dict(c=ch)))
+    prog.append(("res", "middle_block.2", dict(cin=ch, cout=ch, kind="plain")))
+    idx = 0
+    for level in reversed(range(len(channel_mult))):
+        co = channel_mult[level] * C_
+        for i in range(num_res_blocks + 1):
+            ich = chans.pop()
+            prog.append(("res", f"output_blocks.{idx}.0", dict(cin=ch + ich, cout=co, kind="plain", concat=ich)))
+            ch = co
+            if level > 0 and i == num_res_blocks:
+                prog.append(("res", f"output_blocks.{idx}.1", dict(cin=ch, cout=ch, kind="up")))
+            idx += 1
+    prog.append(("head", "out", dict(c=ch)))
+    return prog
+
+
+def conv_table(program):
+    """every convolution that runs on the fused kernel: name -> (Cout, Cin, k, folded, exponent group). A ResBlock's second convolution
+    and its 1x1 skip_connection run as ONE launch and share the pre-scale exponent."""
+    t = {}
+    for kind, name, a in program:
+        if kind == "res":
+            t[name + ".in_layers.2"] = (a["cout"], a["cin"], 3, a["kind"] == "up", name + ".in_layers.2")
+            t[name + ".out_layers.3"] = (a["cout"], a["cout"], 3, False, name + ".out_layers.3")
+            if a["cin"] != a["cout"]:
+                t[name + ".skip_connection"] = (a["cout"], a["cin"], 1, False, name + ".out_layers.3")
+        elif kind == "attn":
+            t[name + ".qkv"] = (3 * a["c"], a["c"], 1, False, name + ".qkv")
+            t[name + ".proj_out"] = (a["c"], a["c"], 1, False, name + ".proj_out")
+    return t
+
+
 class UNetTrainer:
     """Forward + backward + Adam of the conditioned UNet on NHWC device tensors, device-resident: the parameters live in ONE flat fp32
     buffer (`flat`; `p[name]` are views with the reference's state_dict names and shapes), their gradients in a second one (`gflat`,
@@ -67,53 +120,10 @@ class UNetTrainer:
 
     # ------------------------------------------------------------------ program (mirrors UNetModel.__init__, OpenAI_Unet.py:604-797)
     def _build_program(self):
-        C_, prog, chans = self.C, [], []
-        ch, idx = C_, 1
-        prog.append(("in", "input_blocks.0.0", None))
-        chans.append(C_)
-        for level, m in enumerate(self.mult):
-            co = m * C_
-            for _ in range(self.nres):
-                prog.append(("res", f"input_blocks.{idx}.0", dict(cin=ch, cout=co, kind="plain", push=True)))
-                ch = co
-                chans.append(ch)
-                idx += 1
-            if level != len(self.mult) - 1:
-                prog.append(("res", f"input_blocks.{idx}.0", dict(cin=ch, cout=ch, kind="down", push=True)))
-                chans.append(ch)
-                idx += 1
-        prog.append(("res", "middle_block.0", dict(cin=ch, cout=ch, kind="plain")))
-        prog.append(("attn", "middle_block.1", dict(c=ch)))
-        prog.append(("res", "middle_block.2", dict(cin=ch, cout=ch, kind="plain")))
-        idx = 0
-        for level in reversed(range(len(self.mult))):
-            co = self.mult[level] * C_
-            for i in range(self.nres + 1):
-                ich = chans.pop()
-                prog.append(("res", f"output_blocks.{idx}.0", dict(cin=ch + ich, cout=co, kind="plain", concat=ich)))
-                ch = co
-                if level > 0 and i == self.nres:
-                    prog.append(("res", f"output_blocks.{idx}.1", dict(cin=ch, cout=ch, kind="up")))
-                idx += 1
-        prog.append(("head", "out", dict(c=ch)))
-        return prog
+        return unet_program(self.C, self.mult, self.nres)
 
     def _conv_table(self):
-        """every convolution that runs on the fused kernel: name -> (Cout, Cin, k, folded, exponent group). A ResBlock's second convolution
-        and its 1x1 skip_connection run as ONE launch and share the pre-scale exponent."""
-        t = {}
-        if "input_blocks.0.0.weight" not in self.p:
-            return t
-        for kind, name, a in self.program:
-            if kind == "res":
-                t[name + ".in_layers.2"] = (a["cout"], a["cin"], 3, a["kind"] == "up", name + ".in_layers.2")
-                t[name + ".out_layers.3"] = (a["cout"], a["cout"], 3, False, name + ".out_layers.3")
-                if a["cin"] != a["cout"]:
-                    t[name + ".skip_connection"] = (a["cout"], a["cin"], 1, False, name + ".out_layers.3")
-            elif kind == "attn":
-                t[name + ".qkv"] = (3 * a["c"], a["c"], 1, False, name + ".qkv")
-                t[name + ".proj_out"] = (a["c"], a["c"], 1, False, name + ".proj_out")
-        return t
+        return conv_table(self.program) if "input_blocks.0.0.weight" in self.p else {}
 
     # ------------------------------------------------------------------ handle, packed weights
     def _fit(self, B, H, W):

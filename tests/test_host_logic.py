@@ -450,3 +450,26 @@ def test_conv_lds_images_are_bank_conflict_free():
                     a32.append(16 * aslot(q, sp, c4 >> 1) + 8 * (c4 & 1))
                 assert _write_b64_cycles(a16) == 4 and _write_b64_cycles(a32) == 4
 
+
+
+def test_training_program_covers_the_state_dict(synth):
+    """host logic of the training step (training.unet_program / conv_table): the operator sequence mirrors UNetModel's construction
+    (reference OpenAI_Unet.py:604-797) -- every convolution, GroupNorm and embedding Linear of the reference's state_dict is visited once,
+    with the channel counts of its weight tensor, and the skip stack balances (each pushed tensor is popped by exactly one output block)"""
+    tr = load_pkg("training")
+    for mult, nres in (((1, 2, 2), 3), ((1, 2, 4), 2)):
+        prog = tr.unet_program(128, mult, nres)
+        tab = tr.conv_table(prog)
+        shapes = synth.unet_param_shapes(model_channels=128, channel_mult=mult, num_res_blocks=nres)
+        for k, (co, ci, ks, _folded, _grp) in tab.items():
+            assert tuple(shapes[k + ".weight"][:2]) == (co, ci) and shapes[k + ".weight"][2] == ks, k
+        convs = {k[:-7] for k, sh in shapes.items() if k.endswith(".weight") and len(sh) >= 3}
+        assert convs - set(tab) == {"input_blocks.0.0", "out.2"}          # the two one-channel convolutions have their own kernels
+        pushed = 1 + sum(1 for kind, _n, a in prog if kind == "res" and a.get("push"))
+        popped = [a["concat"] for kind, _n, a in prog if kind == "res" and a.get("concat")]
+        assert pushed == len(popped)
+        visited = {n for _k, n, _a in prog}
+        for k in shapes:
+            if k.startswith(("time_embed", "label_emb")):
+                continue
+            assert any(k.startswith(v + ".") for v in visited), k
