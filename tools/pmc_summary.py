@@ -49,7 +49,8 @@ res["hbm_fetch_bytes_per_launch"] = fetch
 res["hbm_write_bytes_per_launch"] = write
 res["bytes_per_launch"] = fetch + write
 json.dump(res, open(out, "w"), indent=1)
-json.dump({"bytes_per_launch": fetch + write, "fetch": fetch, "write": write,
-           "note": "rocprofv3 FETCH_SIZE x2 (gfx950 wide-read correction) + WRITE_SIZE, average over the conv3x3 launches of 50 reverse steps, B=64 128x128"},
-          open(os.path.join(os.path.dirname(out), os.path.basename(out).split("_")[0] + "_conv3x3_hbm_traffic.json"), "w"), indent=1)
+if KEY.startswith("conv_split_kernel<9"):       # only the headline kernel's run feeds bench.py's roofline.traffic
+  json.dump({"bytes_per_launch": fetch + write, "fetch": fetch, "write": write,
+             "note": "rocprofv3 FETCH_SIZE x2 (gfx950 wide-read correction) + WRITE_SIZE, average over the conv3x3 launches of 50 reverse steps, B=64 128x128"},
+            open(os.path.join(os.path.dirname(out), os.path.basename(out).split("_")[0] + "_conv3x3_hbm_traffic.json"), "w"), indent=1)
 print(json.dumps(res, indent=1))
