@@ -11,7 +11,7 @@ oracle/encoder_oracle.py's restatement (tests/test_gpu_encoder_training.py)."""
 from __future__ import annotations
 
 import ctypes as C
-from typing import Dict, List, Optional
+from typing import Dict, Optional
 
 import torch
 

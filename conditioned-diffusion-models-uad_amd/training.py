@@ -17,7 +17,6 @@ import ctypes as C
 import math
 from typing import Dict, List, Optional
 
-import numpy as np
 import torch
 
 from . import schedule as _schedule
@@ -199,11 +198,11 @@ class UNetTrainer:
         self._ck(self.lib.cddpm_op_linear(self.h, _p(x), _p(w), _p(b), M, w.shape[0], K, int(silu_in), _p(y), self._s()), "op_linear")
         return y
 
-    def linear_bwd(self, x, name, dy, silu_in=False, need_dx=True):
+    def linear_bwd(self, x, name, dy, silu_in=False):
         """writes dW, db of Linear `name` into the gradient buffer, returns dx"""
         w = self.p[name + ".weight"]
         M, K = x.shape
-        dx = self._new(M, K) if need_dx else self._new(M, K)
+        dx = self._new(M, K)
         self._ck(self.lib.cddpm_op_linear_backward(self.h, _p(x), _p(w), _p(dy), M, w.shape[0], K, int(bool(silu_in)), _p(self.g[name + ".weight"]),
                                                    _p(self.g[name + ".bias"]), _p(dx), self._s()), "op_linear_backward")
         return dx
