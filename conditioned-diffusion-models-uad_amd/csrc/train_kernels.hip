@@ -587,19 +587,24 @@ struct WgradImgArgs {
     int P;
 };
 
-template <int NS>
+template <int TAPS, int NS>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_img_kernel(const WgradImgArgs a) {
-    constexpr int TX = 8, TY = 2, NPX = 16, PW = 10, PH = 4, NHP = 40, CK = 32, TAPS = 9;
+    // TAPS = 9: 32 input channels per workgroup, wave = (co 32-block) x (ci 16-block), all nine taps: 18 accumulator tiles of 16 x 16
+    // TAPS = 1: 64 input channels per workgroup (no halo, no tap reuse: the wider tile halves the staging per MFMA), wave = (co 32-block) x
+    //           (ci 32-block): 4 accumulator tiles
+    constexpr int PAD = (TAPS == 9) ? 1 : 0;
+    constexpr int TX = 8, TY = 2, NPX = 16, PW = TX + 2 * PAD, PH = TY + 2 * PAD, NHP = PW * PH, CK = (TAPS == 9) ? 32 : 64;
+    constexpr int NJ = (TAPS == 9) ? 1 : 2;                                  // ci 16-blocks per wave
     // 16-byte units per channel row: pitch = 2 (mod 8). ds_read_b128 serves a wave in four groups of 16 lanes, each holding the 16 channel
     // rows of a fragment once, 8 of them (r) at k-group g and the other 8 (r + 8) at g + 1: rows r and r + 8 then share an even 16-byte bank
     // slot, and the +1 of the second half moves it to the odd one -- conflict-free (a pitch of 41 measured 41 % conflict cycles)
     constexpr int APITCH = NHP + 2, DPITCH = NPX + 2;
-    constexpr int NA = NS * CK * NHP, ND = NS * 64 * NPX;                   // units per tile: 2560 + 2048 (NS = 2)
+    constexpr int NA = NS * CK * NHP, ND = NS * 64 * NPX;                   // units per tile: 2560 + 2048 (3x3, NS = 2)
     constexpr int LA = NA / 256, LD = ND / 256;                             // per thread: 10 + 8
     __shared__ uint4 actL[NS][CK * APITCH];
     __shared__ uint4 dyL[NS][64 * DPITCH];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int cw = wave & 1, cj = wave >> 1;          // wave = (co 32-block) x (ci 16-block), all nine taps: 18 accumulator tiles of 16 x 16
+    const int cw = wave & 1, cj = wave >> 1;
     const int r = lane & 15, g = lane >> 4;
     const int nchunk = a.Cin / CK, ncb = a.Cout >> 6, HW = a.H * a.W;
     // workgroups go round-robin over the 8 XCDs (each with its own L2): the ncb x nchunk workgroups of one pixel range p share its dy tiles
@@ -611,11 +616,13 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_img_kernel(const WgradImgAr
     const int ntile = a.G * tpg;
     const int t0 = (int)((long long)ntile * p / a.P), t1 = (int)((long long)ntile * (p + 1) / a.P);
     const size_t aplane = (size_t)a.G * a.Cin * HW, dplane = (size_t)a.G * a.Cout * HW;
-    wg_v4f acc[2][9];
+    wg_v4f acc[2][NJ][TAPS];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int t = 0; t < 9; ++t) acc[i][t] = wg_v4f{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int t = 0; t < TAPS; ++t) acc[i][j][t] = wg_v4f{0.f, 0.f, 0.f, 0.f};
     uint4 ra[LA], rd[LD];
     auto fetch = [&](int tile) {
         const int grp = tile / tpg, tt = tile - grp * tpg;
@@ -623,7 +630,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_img_kernel(const WgradImgAr
 #pragma unroll
         for (int i = 0; i < LA; ++i) {
             const int e = tid + 256 * i, s2 = e / (CK * NHP), rem = e - s2 * (CK * NHP), ch = rem / NHP, hp = rem - ch * NHP;
-            const int gy = y0 - 1 + hp / PW, gx = x0 - 1 + hp % PW;
+            const int gy = y0 - PAD + hp / PW, gx = x0 - PAD + hp % PW;
             ra[i] = make_uint4(0u, 0u, 0u, 0u);
             if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
                 ra[i] = a.act[s2 * aplane + ((size_t)grp * a.Cin + chunk * CK + ch) * HW + gy * a.W + gx];
@@ -660,40 +667,52 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_img_kernel(const WgradImgAr
 #pragma unroll
                 for (int i = 0; i < 2; ++i) fa[s2][i] = __builtin_bit_cast(wg_f16x8, dyL[s2][(cw * 32 + i * 16 + r) * DPITCH + ty * TX + tx]);
             // fragments of tap t + 1 are read while tap t multiplies
-            wg_f16x8 fb[2][NS];
+            wg_f16x8 fb[2][NS][NJ];
 #pragma unroll
-            for (int s2 = 0; s2 < NS; ++s2) fb[0][s2] = __builtin_bit_cast(wg_f16x8, actL[s2][(cj * 16 + r) * APITCH + ty * PW + tx]);
+            for (int s2 = 0; s2 < NS; ++s2)
 #pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                if (t < 8) {
+                for (int j = 0; j < NJ; ++j)
+                    fb[0][s2][j] = __builtin_bit_cast(wg_f16x8, actL[s2][((cj * NJ + j) * 16 + r) * APITCH + ty * PW + tx]);
+#pragma unroll
+            for (int t = 0; t < TAPS; ++t) {
+                if (t + 1 < TAPS) {
                     const int ky = (t + 1) / 3, kx = (t + 1) - 3 * ky;
 #pragma unroll
                     for (int s2 = 0; s2 < NS; ++s2)
-                        fb[(t + 1) & 1][s2] = __builtin_bit_cast(wg_f16x8, actL[s2][(cj * 16 + r) * APITCH + (ty + ky) * PW + tx + kx]);
+#pragma unroll
+                        for (int j = 0; j < NJ; ++j)
+                            fb[(t + 1) & 1][s2][j] =
+                                __builtin_bit_cast(wg_f16x8, actL[s2][((cj * NJ + j) * 16 + r) * APITCH + (ty + ky) * PW + tx + kx]);
                 }
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    if (NS == 2) {
-                        acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[NS - 1][i], fb[t & 1][0], acc[i][t], 0, 0, 0);
-                        acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[0][i], fb[t & 1][NS - 1], acc[i][t], 0, 0, 0);
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) {
+                        if (NS == 2) {
+                            acc[i][j][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[NS - 1][i], fb[t & 1][0][j], acc[i][j][t], 0, 0, 0);
+                            acc[i][j][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[0][i], fb[t & 1][NS - 1][j], acc[i][j][t], 0, 0, 0);
+                        }
+                        acc[i][j][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[0][i], fb[t & 1][0][j], acc[i][j][t], 0, 0, 0);
                     }
-                    acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[0][i], fb[t & 1][0], acc[i][t], 0, 0, 0);
+                if (TAPS == 9) {
+                    // keep the program order "reads of tap t + 1, then the MFMAs of tap t" (the scheduler otherwise clusters the reads of two
+                    // taps right in front of their MFMAs and the LDS latency is exposed every 12 MFMAs)
+                    if (t < 8) __builtin_amdgcn_sched_group_barrier(0x100, NS, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, NS == 2 ? 6 : 2, 0);
                 }
-                // keep the program order "reads of tap t + 1, then the MFMAs of tap t" (the scheduler otherwise clusters the reads of two
-                // taps right in front of their MFMAs and the LDS latency is exposed every 12 MFMAs)
-                if (t < 8) __builtin_amdgcn_sched_group_barrier(0x100, NS, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, NS == 2 ? 6 : 2, 0);
             }
         }
     }
     float* o = a.part + ((((size_t)p * ncb + cb) * nchunk + chunk) * 64) * TAPS * CK;
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+    for (int t = 0; t < TAPS; ++t)
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-                o[((size_t)(cw * 32 + i * 16 + 4 * g + e) * TAPS + t) * CK + cj * 16 + r] = acc[i][t][e];
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    o[((size_t)(cw * 32 + i * 16 + 4 * g + e) * TAPS + t) * CK + (cj * NJ + j) * 16 + r] = acc[i][j][t][e];
 }
 
 // convolution weight-gradient family: CDDPM_WGRAD = h3 (default: fp16 two-term split, fp32-grade), h1 (plain fp16 operands), f32 (the
@@ -770,22 +789,24 @@ static void bias_grad_run(const float* dy, long long npix, int C, float* db, dou
 
 int conv_wgrad_parts(int B, int H, int W, int Cin, int Cout, int taps) {
     // enough workgroups for two per CU, at most one tile each, at least 1
-    // mirrors launch_conv_wgrad's choice of kernel: the split families tile (8 samples) x (2 x 8 pixels) and 32-channel chunks
-    const bool f32k = wgrad_mode() == 0 || (taps == 1 && Cin % 64 == 0 && H % 4 == 0 && H >= 4);
+    // mirrors launch_conv_wgrad's choice of kernel: the split families tile (8 samples) x (2 x 8 pixels); chunks of 32 input channels
+    // (3x3, and the single-pass 1x1 fallback) or 64 (1x1 over images, and the fp32 family's 1x1)
+    const bool f32k = wgrad_mode() == 0;
+    const bool img = !f32k && (taps == 9 || Cin % 64 == 0);
     const int ntile = !f32k ? ((B + 7) / 8) * ((H + 1) / 2) * ((W + 7) / 8) : B * (H / 4) * ((W + 31) / 32);
-    const int per = (Cout / 64) * (Cin / ((taps == 9 || !f32k) ? 32 : 64));
+    const int per = (Cout / 64) * (Cin / ((taps == 9 || (!f32k && !img)) ? 32 : 64));
     int P = (512 + per - 1) / per;
     if (P > ntile) P = ntile;
     if (P > 64) P = 64;
     if (P < 1) P = 1;
-    if (wgrad_mode() != 0 && taps == 9) P = (P + 7) & ~7;      // the two-pass kernel spreads its pixel ranges over the 8 XCDs
+    if (img) P = (P + 7) & ~7;      // the two-pass kernel spreads its pixel ranges over the 8 XCDs
     return P;
 }
 
 // scratch of the two-pass 3x3 family beyond the partial tiles: the two k-images, in 16-byte units (0: this call does not use them)
 size_t conv_wgrad_image_units(int B, int H, int W, int Cin, int Cout, int taps) {
     const int mode = wgrad_mode();
-    if (mode == 0 || taps != 9) return 0;
+    if (mode == 0 || (taps == 1 && Cin % 64)) return 0;
     return (size_t)(mode == 2 ? 2 : 1) * ((B + 7) / 8) * (size_t)(Cin + Cout) * H * W;
 }
 
@@ -797,7 +818,7 @@ void launch_conv_wgrad(const float* x0, int C0, const float* x1, int C1, const f
     const int Cin = C0 + C1, mode = wgrad_mode();
     const int G = (B + 7) / 8;
     int CK = 32;
-    if (mode != 0 && taps == 9) {
+    if (mode != 0 && (taps == 9 || Cin % 64 == 0)) {
         // pass 1: the two k-images; pass 2: the GEMM over them
         const int NS = mode == 2 ? 2 : 1;
         uint4* aimg = static_cast<uint4*>(images);
@@ -810,11 +831,16 @@ void launch_conv_wgrad(const float* x0, int C0, const float* x1, int C1, const f
         hipLaunchKernelGGL(wgrad_image_kernel, dim3((H * W + 7) / 8, (Cout + 127) / 128, G), dim3(256), 0, stream, ia);
         WgradImgArgs w;
         w.act = aimg; w.dy = dimg; w.Cin = Cin; w.Cout = Cout; w.H = H; w.W = W; w.G = G; w.part = part; w.P = P;
-        const unsigned grid = (unsigned)(P * (Cout / 64) * (Cin / 32));
-        if (NS == 2) hipLaunchKernelGGL(conv_wgrad_img_kernel<2>, dim3(grid), dim3(256), 0, stream, w);
-        else         hipLaunchKernelGGL(conv_wgrad_img_kernel<1>, dim3(grid), dim3(256), 0, stream, w);
-    } else if (mode == 0 || (taps == 1 && Cin % 64 == 0 && H % 4 == 0 && H >= 4 && (C1 == 0 || C0 % 64 == 0))) {
-        // fp32-MFMA kernel: the 1x1 convolutions (4 % of the weight-gradient FLOPs) run faster on it than on the single-pass split kernel
+        CK = taps == 9 ? 32 : 64;
+        const unsigned grid = (unsigned)(P * (Cout / 64) * (Cin / CK));
+        if (taps == 9) {
+            if (NS == 2) hipLaunchKernelGGL((conv_wgrad_img_kernel<9, 2>), dim3(grid), dim3(256), 0, stream, w);
+            else         hipLaunchKernelGGL((conv_wgrad_img_kernel<9, 1>), dim3(grid), dim3(256), 0, stream, w);
+        } else {
+            if (NS == 2) hipLaunchKernelGGL((conv_wgrad_img_kernel<1, 2>), dim3(grid), dim3(256), 0, stream, w);
+            else         hipLaunchKernelGGL((conv_wgrad_img_kernel<1, 1>), dim3(grid), dim3(256), 0, stream, w);
+        }
+    } else if (mode == 0) {
         CK = taps == 9 ? 32 : 64;
         const unsigned grid = (unsigned)(P * (Cout / 64) * (Cin / CK));
         if (taps == 9) hipLaunchKernelGGL(conv_wgrad_kernel<9>, dim3(grid), dim3(256), 0, stream, a);
