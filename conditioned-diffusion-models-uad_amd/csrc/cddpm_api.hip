@@ -1321,8 +1321,8 @@ int cddpm_op_pack_conv(cddpm_handle h, const float* w_dev, int Cout, int Cin, in
 
 int cddpm_op_conv_packed(cddpm_handle h, const float* src0, int C0, const float* src1, int C1, const float* coef_dev, int silu, int folded_up,
                          const void* packed_dev, int scale_exp, const float* bias_dev, int Cout, int ksize, const float* res_dev,
-                         int res_upsample, const float* skip_dev, int S0, const void* skip_packed_dev, float* out_dev, int B, int H, int W,
-                         void* stream) {
+                         int res_upsample, const float* skip_dev, int S0, const void* skip_packed_dev, float* out_dev, float* stats_dev, int B,
+                         int H, int W, void* stream) {
     if (!h) return -1;
     const int Cin = C0 + C1;
     if (conv_mode() != 2) return fail(h, "cddpm_op_conv_packed: default convolution family (CDDPM_CONV=h3) only");
@@ -1341,7 +1341,26 @@ int cddpm_op_conv_packed(cddpm_handle h, const float* src0, int C0, const float*
     a.skip0 = skip_dev; a.S0 = skip_dev ? S0 : 0; a.skip_wpk = static_cast<const float*>(skip_packed_dev);
     a.wscale_inv = ldexpf(1.0f, -scale_exp);
     a.out = out_dev; a.B = B; a.H = H; a.W = W; a.Cout = Cout; a.taps = folded_up ? 4 : ksize * ksize;
+    a.stats = stats_dev;       // [B][cddpm_stat_records(H, W, folded_up ? 1 : 0)][Cout][2]: the output's GroupNorm statistics records, for free
     launch_conv(a, (hipStream_t)stream);
+    HIPCHECK(h, hipGetLastError());
+    return 0;
+}
+
+int cddpm_op_gn_coef_rec(cddpm_handle h, const float* rec0_dev, int n0, int C0, const float* rec1_dev, int n1, int C1, const float* gamma_host,
+                         const float* beta_host, const float* film_dev, float* coef_dev, int B, int HW, void* stream) {
+    if (!h) return -1;
+    const int C = C0 + C1;
+    if (C0 % 4 || C1 % 4 || C % 32 || C > MAX_CONCAT_CHANNELS || C0 > 1024 || C1 > 1024 || C0 <= 0 || n0 < 1 || (C1 > 0 && (n1 < 1 || !rec1_dev)))
+        return fail(h, "cddpm_op_gn_coef_rec: unsupported channels / record counts");
+    if (!rec0_dev || !gamma_host || !beta_host || !coef_dev) return fail(h, "cddpm_op_gn_coef_rec: NULL argument");
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHECK(h, hipSetDevice(h->device));
+    OpScratch sc(h, s);
+    const float* g = sc.param(gamma_host, C);
+    const float* bt = sc.param(beta_host, C);
+    SCRATCH_CHECK(sc)
+    launch_gn_finalize(rec0_dev, C0, n0, C1 ? rec1_dev : nullptr, C1, C1 ? n1 : 0, B, HW, g, bt, nullptr, nullptr, 0, 0, nullptr, film_dev, coef_dev, s);
     HIPCHECK(h, hipGetLastError());
     return 0;
 }
@@ -1817,24 +1836,25 @@ int cddpm_op_enc_avgpool(cddpm_handle h, const float* x_dev, float* g_dev, int B
 
 int cddpm_op_gn_silu_backward(cddpm_handle h, const float* x_dev, const float* da_dev, const float* gamma_host,
                               const float* beta_host, const float* film_dev, int silu, float* dx_dev, float* dgamma_dev,
-                              float* dbeta_dev, float* dfilm_dev, int B, int HW, int C, void* stream) {
+                              float* dbeta_dev, float* dfilm_dev, const float* rec_dev, int nrec, int B, int HW, int C, void* stream) {
     if (!h) return -1;
-    if (C % 32 || C <= 0 || C > 1024 || B < 1 || HW < 1) return fail(h, "cddpm_op_gn_silu_backward: unsupported shape (C %d)", C);
+    if (C % 32 || C <= 0 || C > 1024 || B < 1 || HW < 1 || (rec_dev && nrec < 1))
+        return fail(h, "cddpm_op_gn_silu_backward: unsupported shape (C %d)", C);
     if (!x_dev || !da_dev || !gamma_host || !beta_host || !dx_dev || !dgamma_dev || !dbeta_dev || (film_dev && !dfilm_dev))
         return fail(h, "cddpm_op_gn_silu_backward: NULL argument");
     hipStream_t s = (hipStream_t)stream;
     HIPCHECK(h, hipSetDevice(h->device));
     const int ns = gn_nsplit(B, HW);
     OpScratch sc(h, s);
-    float* rec = sc.n<float>((size_t)B * ns * C * 2);
+    float* rec = rec_dev ? nullptr : sc.n<float>((size_t)B * ns * C * 2);
     const float* g = sc.param(gamma_host, C);
     const float* bt = sc.param(beta_host, C);
     float* planes = sc.n<float>((size_t)4 * B * C);
     float* out_bc = sc.n<float>((size_t)4 * B * C);
     double* part = sc.n<double>((size_t)B * ns * C * 2);
     SCRATCH_CHECK(sc)
-    launch_gn_partial(x_dev, C, B, HW, ns, rec, s);
-    launch_gn_bwd_planes(rec, ns, g, bt, film_dev, B, C, HW, planes, s);
+    if (!rec_dev) launch_gn_partial(x_dev, C, B, HW, ns, rec, s);      // statistics records of x: given (kept from the forward pass) or swept here
+    launch_gn_bwd_planes(rec_dev ? rec_dev : rec, rec_dev ? nrec : ns, g, bt, film_dev, B, C, HW, planes, s);
     launch_gn_silu_backward(x_dev, da_dev, planes, g, bt, film_dev, silu, B, C, HW, ns, part, out_bc, dx_dev, dgamma_dev, dbeta_dev,
                             dfilm_dev, s);
     HIPCHECK(h, hipGetLastError());

@@ -161,39 +161,47 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
     *reinterpret_cast<float4*>(dx + off) = o;
 }
 
-// forward statistics for the standalone op: planes[0] = mean_g, [1] = rstd_g, [2] = g', [3] = b' from fp32 (sum, sum of squares) records
+// forward statistics for the standalone op: planes[0] = mean_g, [1] = rstd_g, [2] = g', [3] = b' from fp32 (sum, sum of squares) records.
+// Four workgroups per sample (8 of the 32 groups each); a workgroup's 256 threads = (channel, record slice): the records of a 128 x 128
+// convolution output are 64 per sample, which one thread per channel walked serially (46 us per launch when the records came from the
+// convolution epilogues instead of the 2 ... 8 of a sweep).
 __global__ __launch_bounds__(256) void gn_bwd_planes_kernel(const float* __restrict__ rec, int nrec, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, const float* __restrict__ film, int B, int C,
                                                             int HW, float* __restrict__ planes) {
-    __shared__ double sS[1024], sQ[1024];
-    __shared__ float gmu[32], grs[32];
+    __shared__ double sS[256], sQ[256];
+    __shared__ float gmu[8], grs[8];
     const int tid = threadIdx.x, b = blockIdx.x;
-    for (int c = tid; c < C; c += 256) {
-        double s = 0, q = 0;
-        for (int r = 0; r < nrec; ++r) {
-            const float* p = rec + (((size_t)b * nrec + r) * C + c) * 2;
+    const int Cq = C >> 2, c0 = blockIdx.y * Cq, cpg = C >> 5;          // this workgroup's channels: 8 groups
+    const int nsl = 256 / Cq > 0 ? 256 / Cq : 1;                         // record slices (Cq <= 256)
+    const int cl = tid % Cq, sl = tid / Cq;
+    double s = 0, q = 0;
+    if (sl < nsl)
+        for (int r = sl; r < nrec; r += nsl) {
+            const float* p = rec + (((size_t)b * nrec + r) * C + c0 + cl) * 2;
             s += p[0]; q += p[1];
         }
-        sS[c] = s; sQ[c] = q;
+    // fold the slices in order through LDS, one slice per round
+    for (int k = 0; k < nsl; ++k) {
+        if (sl == k) { sS[cl] = (k ? sS[cl] : 0.0) + s; sQ[cl] = (k ? sQ[cl] : 0.0) + q; }
+        __syncthreads();
     }
-    __syncthreads();
-    const int cpg = C >> 5;
-    if (tid < 32) {
-        double s = 0, q = 0;
-        for (int i = 0; i < cpg; ++i) { s += sS[tid * cpg + i]; q += sQ[tid * cpg + i]; }
-        const double n = (double)cpg * (double)HW, mean = s / n;
-        double var = q / n - mean * mean;
+    if (tid < 8) {
+        double gs = 0, gq = 0;
+        for (int i = 0; i < cpg; ++i) { gs += sS[tid * cpg + i]; gq += sQ[tid * cpg + i]; }
+        const double n = (double)cpg * (double)HW, mean = gs / n;
+        double var = gq / n - mean * mean;
         if (var < 0) var = 0;
         gmu[tid] = (float)mean;
         grs[tid] = (float)(1.0 / sqrt(var + 1e-5));
     }
     __syncthreads();
     const size_t pc = (size_t)B * C;
-    for (int c = tid; c < C; c += 256) {
+    for (int i = tid; i < Cq; i += 256) {
+        const int c = c0 + i;
         const size_t bc = (size_t)b * C + c;
         const float sc = film ? film[(size_t)b * 2 * C + c] : 0.f, sh = film ? film[(size_t)b * 2 * C + C + c] : 0.f;
-        planes[bc] = gmu[c / cpg];
-        planes[pc + bc] = grs[c / cpg];
+        planes[bc] = gmu[i / cpg];
+        planes[pc + bc] = grs[i / cpg];
         planes[2 * pc + bc] = gamma[c] * (1.0f + sc);
         planes[3 * pc + bc] = beta[c] * (1.0f + sc) + sh;
     }
@@ -201,7 +209,7 @@ __global__ __launch_bounds__(256) void gn_bwd_planes_kernel(const float* __restr
 
 void launch_gn_bwd_planes(const float* rec, int nrec, const float* gamma, const float* beta, const float* film, int B, int C, int HW,
                           float* planes, hipStream_t stream) {
-    hipLaunchKernelGGL(gn_bwd_planes_kernel, dim3(B), dim3(256), 0, stream, rec, nrec, gamma, beta, film, B, C, HW, planes);
+    hipLaunchKernelGGL(gn_bwd_planes_kernel, dim3(B, 4), dim3(256), 0, stream, rec, nrec, gamma, beta, film, B, C, HW, planes);
 }
 
 void launch_gn_silu_backward(const float* x, const float* da, const float* planes, const float* gamma, const float* beta,

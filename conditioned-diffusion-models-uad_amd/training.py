@@ -208,34 +208,57 @@ class UNetTrainer:
         return dx
 
     def gn_coef(self, x0, x1, name, film=None):
+        """GroupNorm (+ FiLM) coefficient planes of cat[x0, x1]; the statistics come from the records the producing convolutions wrote in
+        their epilogues (self.rec) where both sources have them, else from a sweep over the tensors"""
         B, HW, C0 = x0.shape[0], x0.shape[1] * x0.shape[2], x0.shape[-1]
         C1 = x1.shape[-1] if x1 is not None else 0
         coef = self._new(3, B, C0 + C1)
-        self._ck(self.lib.cddpm_op_gn_coef(self.h, _p(x0), C0, _p(x1), C1, _p(self.p[name + ".weight"]), _p(self.p[name + ".bias"]), _p(film),
-                                           _p(coef), B, HW, self._s()), "op_gn_coef")
+        r0, r1 = self.rec.get(x0.data_ptr()), (self.rec.get(x1.data_ptr()) if x1 is not None else None)
+        if r0 is not None and (x1 is None or r1 is not None):
+            self._ck(self.lib.cddpm_op_gn_coef_rec(self.h, _p(r0), r0.shape[1], C0, _p(r1), r1.shape[1] if r1 is not None else 0, C1,
+                                                   _p(self.p[name + ".weight"]), _p(self.p[name + ".bias"]), _p(film), _p(coef), B, HW, self._s()),
+                     "op_gn_coef_rec")
+        else:
+            self._ck(self.lib.cddpm_op_gn_coef(self.h, _p(x0), C0, _p(x1), C1, _p(self.p[name + ".weight"]), _p(self.p[name + ".bias"]), _p(film),
+                                               _p(coef), B, HW, self._s()), "op_gn_coef")
         return coef
 
-    def gn_bwd(self, x, da, name, film=None, silu=True):
-        """backward of act(GroupNorm32(x) (1 + scale) + shift): dgamma / dbeta go to the gradient buffer; -> (dx, dfilm or None)"""
+    def gn_bwd(self, x, da, name, film=None, silu=True, rec=None):
+        """backward of act(GroupNorm32(x) (1 + scale) + shift): dgamma / dbeta go to the gradient buffer; -> (dx, dfilm or None).
+        rec: x's statistics records kept from the forward pass (else they are swept again)"""
         B, H, W, Cc = x.shape
         dx = torch.empty_like(x)
         dfilm = self._new(B, 2 * Cc) if film is not None else None
         self._ck(self.lib.cddpm_op_gn_silu_backward(self.h, _p(x), _p(da), _p(self.p[name + ".weight"]), _p(self.p[name + ".bias"]), _p(film),
                                                     int(bool(silu)), _p(dx), _p(self.g[name + ".weight"]), _p(self.g[name + ".bias"]), _p(dfilm),
-                                                    B, H * W, Cc, self._s()), "op_gn_silu_backward")
+                                                    _p(rec), rec.shape[1] if rec is not None else 0, B, H * W, Cc, self._s()),
+                 "op_gn_silu_backward")
         return dx, dfilm
 
-    def conv(self, name, x0, x1=None, coef=None, silu=False, res=None, res_up=False, skip=None, skip_name=None, bias=None):
+    def rec_of(self, x0, x1=None):
+        """statistics records of cat[x0, x1] when both sources have records of the same count (record tensors concatenate along channels)"""
+        r0 = self.rec.get(x0.data_ptr())
+        if x1 is None:
+            return r0
+        r1 = self.rec.get(x1.data_ptr())
+        if r0 is None or r1 is None or r0.shape[1] != r1.shape[1]:
+            return None
+        return torch.cat([r0, r1], dim=2).contiguous()
+
+    def conv(self, name, x0, x1=None, coef=None, silu=False, res=None, res_up=False, skip=None, skip_name=None, bias=None, stats=True):
         """fused forward convolution `name` on its packed image: conv_k(act(cat[x0, x1])) [+ conv1x1(skip)] + bias [+ res]"""
         co, ci, ks, folded, _g = self._convs[name]
         B, h_, w_, C0 = x0.shape
         H, W = (2 * h_, 2 * w_) if folded else (h_, w_)
         out = self._new(B, H, W, co)
         b = bias if bias is not None else self.p[name + ".bias"]
+        rec = self._new(B, self.lib.cddpm_stat_records(H, W, 1 if folded else 0), co, 2) if stats else None
         self._ck(self.lib.cddpm_op_conv_packed(
             self.h, _p(x0), C0, _p(x1), x1.shape[-1] if x1 is not None else 0, _p(coef), int(bool(silu)), int(folded), _p(self.pk[name]), self.wexp[name],
             _p(b), co, ks, _p(res), int(bool(res_up)), _p(skip), skip.shape[-1] if skip is not None else 0,
-            _p(self.pk[skip_name]) if skip_name else None, _p(out), B, H, W, self._s()), "op_conv_packed")
+            _p(self.pk[skip_name]) if skip_name else None, _p(out), _p(rec), B, H, W, self._s()), "op_conv_packed")
+        if rec is not None:
+            self.rec[out.data_ptr()] = rec          # GroupNorm statistics of the output, written by the convolution's epilogue
         return out
 
     def dgrad(self, name, dy):
@@ -244,7 +267,7 @@ class UNetTrainer:
         B, H, W, _c = dy.shape
         dx = self._new(B, H, W, ci)
         self._ck(self.lib.cddpm_op_conv_packed(self.h, _p(dy), co, None, 0, None, 0, 0, _p(self.pkT[name]), self.wexp[name], None, ci, ks, None, 0,
-                                               None, 0, None, _p(dx), B, H, W, self._s()), "op_conv_packed (input gradient)")
+                                               None, 0, None, _p(dx), None, B, H, W, self._s()), "op_conv_packed (input gradient)")
         return dx
 
     def wgrad(self, name, x0, x1, coef, silu, dy, upsample=False, bias=True):
@@ -278,6 +301,7 @@ class UNetTrainer:
         p, sv = self.p, {}
         B, _c, H, W = x.shape
         self._fit(B, H, W)
+        self.rec: Dict[int, torch.Tensor] = {}             # data_ptr of a saved activation -> its GroupNorm statistics records
         x = x.contiguous().float()
         # timestep embedding (util.py:151-171): cos first, float32 arithmetic as torch does
         half = self.C // 2
@@ -303,7 +327,7 @@ class UNetTrainer:
             elif kind == "res":
                 x1 = hs.pop() if a.get("concat") else None
                 film = self.linear(emb, name + ".emb_layers.1", silu_in=True)
-                r = dict(x0=cur, x1=x1, film=film)
+                r = dict(x0=cur, x1=x1, film=film, rec_in=self.rec_of(cur, x1))
                 coef1 = self.gn_coef(cur, x1, name + ".in_layers.0")
                 r["coef1"] = coef1
                 c1, c2 = name + ".in_layers.2", name + ".out_layers.3"
@@ -321,7 +345,7 @@ class UNetTrainer:
                     h1 = self.conv(c1, cur, x1, coef1, True)
                     resid, res_up = cur, False
                 coef2 = self.gn_coef(h1, None, name + ".out_layers.0", film)
-                r.update(h1=h1, coef2=coef2)
+                r.update(h1=h1, coef2=coef2, rec_h1=self.rec_of(h1))
                 if a["cin"] != a["cout"]:
                     xin = cur if x1 is None else torch.cat([cur, x1], dim=-1)
                     r["xin"] = xin
@@ -336,11 +360,11 @@ class UNetTrainer:
             elif kind == "attn":
                 Bc, h_, w_, Cc = cur.shape
                 coefn = self.gn_coef(cur, None, name + ".norm")
-                qkv = self.conv(name + ".qkv", cur, None, coefn, False)
+                qkv = self.conv(name + ".qkv", cur, None, coefn, False, stats=False)
                 att = self._new(Bc, h_, w_, Cc)
                 self._ck(self.lib.cddpm_op_attention(self.h, _p(qkv), _p(att), Bc, h_ * w_, Cc, self._s()), "op_attention")
                 out = self.conv(name + ".proj_out", att, res=cur)
-                sv[name] = dict(x=cur, coefn=coefn, qkv=qkv, att=att)
+                sv[name] = dict(x=cur, coefn=coefn, qkv=qkv, att=att, rec=self.rec_of(cur))
                 cur = out
             else:   # head: GroupNorm -> SiLU -> Conv2d(C -> 1)
                 coefo = self.gn_coef(cur, None, "out.0")
@@ -348,7 +372,7 @@ class UNetTrainer:
                 out = self._new(B, 1, H, W)
                 self._ck(self.lib.cddpm_op_head(self.h, _p(cur), _p(coefo), _p(w9), C.c_float(0.0), _p(p["out.2.bias"]), _p(out), B, H, W, a["c"],
                                                 self._s()), "op_head")
-                sv["out"] = dict(x=cur, coefo=coefo, w9=w9)
+                sv["out"] = dict(x=cur, coefo=coefo, w9=w9, rec=self.rec_of(cur))
                 cur = out
         self.saved = sv
         return cur
@@ -370,7 +394,7 @@ class UNetTrainer:
                 self._ck(self.lib.cddpm_op_chan_image_corr(self.h, _p(r["x"]), _p(r["coefo"]), 1, _p(dout), -1, _p(g["out.2.weight"]), B, H, W, Cc,
                                                            self._s()), "op_chan_image_corr")
                 g["out.2.bias"].copy_(dout.sum().reshape(1))          # one scalar
-                d, _ = self.gn_bwd(r["x"], dact, "out.0")
+                d, _ = self.gn_bwd(r["x"], dact, "out.0", rec=r["rec"])
             elif kind == "attn":
                 r = sv[name]
                 da = self.dgrad(name + ".proj_out", d)
@@ -381,7 +405,7 @@ class UNetTrainer:
                          "op_attention_backward")
                 dn = self.dgrad(name + ".qkv", dqkv)
                 self.wgrad(name + ".qkv", r["x"], None, r["coefn"], False, dqkv)
-                dx, _ = self.gn_bwd(r["x"], dn, name + ".norm", None, False)
+                dx, _ = self.gn_bwd(r["x"], dn, name + ".norm", None, False, rec=r["rec"])
                 d = self.add_(dx, d)
             elif kind == "res":
                 if a.get("push"):        # this op's output also fed a skip connection: add that gradient
@@ -396,24 +420,24 @@ class UNetTrainer:
                 if a["cin"] != a["cout"]:
                     dxs = self.dgrad(name + ".skip_connection", d)            # [B,H,W,Cin] over the concatenation
                     self.wgrad(name + ".skip_connection", x0, x1, None, False, d)
-                dh1, dfilm = self.gn_bwd(h1, da2, name + ".out_layers.0", film)
+                dh1, dfilm = self.gn_bwd(h1, da2, name + ".out_layers.0", film, rec=r["rec_h1"])
                 self.add_(demb, self.linear_bwd(sv["emb"], name + ".emb_layers.1", dfilm, True))       # film = Linear(SiLU(emb))
                 if a["kind"] == "down":
                     dhp = self.dgrad(c1, dh1)
                     self.wgrad(c1, r["hp"], None, None, False, dh1)
                     da1 = self.unpool2(dhp, 0.25)
-                    dx, _ = self.gn_bwd(x0, da1, name + ".in_layers.0")
+                    dx, _ = self.gn_bwd(x0, da1, name + ".in_layers.0", rec=r["rec_in"])
                     self.unpool2(d, 0.25, into=dx)                            # identity skip through avg_pool(x)
                 elif a["kind"] == "up":
                     dau = self.dgrad(c1, dh1)                                 # gradient of the upsampled activation
                     self.wgrad(c1, x0, None, r["coef1"], True, dh1, upsample=True)
                     da1 = self.sumpool2(dau)
-                    dx, _ = self.gn_bwd(x0, da1, name + ".in_layers.0")
+                    dx, _ = self.gn_bwd(x0, da1, name + ".in_layers.0", rec=r["rec_in"])
                     self.sumpool2(d, into=dx)                                 # identity skip through the upsampled x
                 else:
                     da1 = self.dgrad(c1, dh1)
                     self.wgrad(c1, x0, x1, r["coef1"], True, dh1)
-                    dx, _ = self.gn_bwd(r["xin"] if x1 is not None else x0, da1, name + ".in_layers.0")
+                    dx, _ = self.gn_bwd(r["xin"] if x1 is not None else x0, da1, name + ".in_layers.0", rec=r["rec_in"])
                     self.add_(dx, dxs if dxs is not None else d)              # 1x1 skip_connection, or the identity skip
                 if x1 is not None:       # split the gradient of the concatenation: [h | popped skip tensor]
                     c0 = x0.shape[-1]

@@ -322,7 +322,12 @@ int cddpm_op_pack_conv(cddpm_handle h, const float* w_dev, int Cout, int Cin, in
 int cddpm_op_conv_packed(cddpm_handle h, const float* src0_dev, int C0, const float* src1_dev, int C1, const float* coef_dev, int silu,
                          int folded_up, const void* packed_dev, int scale_exp, const float* bias_dev, int Cout, int ksize,
                          const float* res_dev, int res_upsample, const float* skip_dev, int S0, const void* skip_packed_dev,
-                         float* out_dev, int B, int H, int W, void* stream);
+                         float* out_dev, float* stats_dev, int B, int H, int W, void* stream);
+/* stats_dev (or NULL): the output's GroupNorm statistics records [B][cddpm_stat_records(H, W, folded_up ? 1 : 0)][Cout][2], written by the
+ * convolution's epilogue; cddpm_op_gn_coef_rec is cddpm_op_gn_coef on such records (no sweep over the tensors), and
+ * cddpm_op_gn_silu_backward takes them through rec_dev / nrec. */
+int cddpm_op_gn_coef_rec(cddpm_handle h, const float* rec0_dev, int n0, int C0, const float* rec1_dev, int n1, int C1, const float* gamma_host,
+                         const float* beta_host, const float* film_dev, float* coef_dev, int B, int HW, void* stream);
 /* ---- training-mode operators of the context encoder (timm ResNet-50, in_chans = 1; reference src/models/modules/DDPM_encoder.py:21-23,
  * trained jointly with the UNet by src/models/DDPM_2D.py:114-135 / :305-306). NHWC fp32 device tensors, plain fp32 FMA kernels (the encoder is
  * ~5 % of a training step's FLOPs). Strided operators map n -> ceil(n / stride).
@@ -361,7 +366,8 @@ int cddpm_op_enc_avgpool(cddpm_handle h, const float* x_dev, float* g_dev, int B
  * dfilm_dev [B][2C]. The forward statistics are recomputed from x_dev. Everything NHWC fp32. */
 int cddpm_op_gn_silu_backward(cddpm_handle h, const float* x_dev, const float* da_dev, const float* gamma_host,
                               const float* beta_host, const float* film_dev, int silu, float* dx_dev, float* dgamma_dev,
-                              float* dbeta_dev, float* dfilm_dev, int B, int HW, int C, void* stream);
+                              float* dbeta_dev, float* dfilm_dev, const float* rec_dev /* x's statistics records or NULL */, int nrec,
+                              int B, int HW, int C, void* stream);
 
 /* GroupNorm statistics record counts per sample for an H x W tensor (host arithmetic, callable without a GPU):
  * kind 0 = records the fused convolution's epilogue writes, 1 = the folded-upsample convolution's, 2 = the stand-alone
