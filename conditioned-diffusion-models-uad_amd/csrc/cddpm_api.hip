@@ -1724,7 +1724,7 @@ int cddpm_op_chan_image_corr(cddpm_handle h, const float* t_dev, const float* co
                              int B, int H, int W, int C, void* stream) {
     OP_PROLOGUE(t_dev && s_dev && dw_dev && C % 64 == 0 && (sign == 1 || sign == -1), "cddpm_op_chan_image_corr: bad arguments")
     OpScratch sc(h, s);
-    double* part = sc.n<double>((size_t)64 * C * 9);
+    double* part = sc.n<double>((size_t)256 * C * 9);
     SCRATCH_CHECK(sc)
     launch_chan_image_corr(t_dev, coef_dev, silu, s_dev, sign, B, H, W, C, part, dw_dev, s);
     OP_EPILOGUE()

@@ -173,7 +173,7 @@ void launch_linear_backward(const float* x, const float* W, const float* dy, int
 void launch_unpool2(const float* dyp, float* dx, int B, int H, int W, int C, float scale, int accumulate, hipStream_t stream);
 void launch_sumpool2(const float* dy, float* dxp, int B, int H, int W, int C, int accumulate, hipStream_t stream);
 void launch_add_inplace(float* a, const float* b, long long n, hipStream_t stream);
-// dw [C][9] = sum_{b,q} act(T)[b,q,c] * simg[b, q + sign * tap]; part: 64 * C * 9 doubles of scratch
+// dw [C][9] = sum_{b,q} act(T)[b,q,c] * simg[b, q + sign * tap]; part: 256 * C * 9 doubles of scratch
 void launch_chan_image_corr(const float* T, const float* coef, int silu, const float* simg, int sign, int B, int H, int W, int C,
                             double* part, float* dw, hipStream_t stream);
 void launch_head_dgrad(const float* dout, const float* w9, float* dact, int B, int H, int W, int C, hipStream_t stream);
