@@ -93,7 +93,13 @@ class UNetTrainer:
         self.dev = torch.device(device) if device is not None else next(iter(params.values())).device
         self._cfg = dict(model_channels=model_channels, channel_mult=tuple(channel_mult), num_res_blocks=num_res_blocks, cond_dim=cond_dim)
         self.C, self.mult, self.nres, self.cond_dim = model_channels, tuple(channel_mult), num_res_blocks, cond_dim
-        names = list(params)
+        # flat layout: the 27 ResBlocks' emb_layers.1 weights first, in program order and without gaps, then their biases: together they are
+        # ONE [sum 2 Cout, E] matrix (11776 x 1024) -- one Linear forward and one backward per step instead of 27 (the inference engine's
+        # table does the same); then every other tensor, each 256-byte aligned
+        self.program = self._build_program()
+        emb_names = [n + ".emb_layers.1" for kind, n, _a in self.program if kind == "res" and n + ".emb_layers.1.weight" in params]
+        lead = [n + ".weight" for n in emb_names] + [n + ".bias" for n in emb_names]
+        names = lead + [k for k in params if k not in set(lead)]
         sizes = [(int(params[k].numel()) + 63) // 64 * 64 for k in names]       # 256-byte aligned views
         self.flat = torch.zeros(sum(sizes), dtype=torch.float32, device=self.dev)
         self.gflat = torch.zeros_like(self.flat)
@@ -106,7 +112,15 @@ class UNetTrainer:
             self.g[k] = self.gflat[off:off + v.numel()].view(v.shape)
             self.p[k].copy_(v.detach().to(self.dev, torch.float32))
             off += n
-        self.program = self._build_program()
+        self.emb_off, self.emb_rows = {}, 0
+        if emb_names and all(params[n + ".weight"].numel() % 64 == 0 and params[n + ".bias"].numel() % 64 == 0 for n in emb_names):
+            E = params[emb_names[0] + ".weight"].shape[1]
+            for n in emb_names:
+                self.emb_off[n[:-len(".emb_layers.1")]] = self.emb_rows
+                self.emb_rows += params[n + ".weight"].shape[0]
+            nw = self.emb_rows * E
+            self.emb_w, self.emb_gw = self.flat[:nw].view(self.emb_rows, E), self.gflat[:nw].view(self.emb_rows, E)
+            self.emb_b, self.emb_gb = self.flat[nw:nw + self.emb_rows], self.gflat[nw:nw + self.emb_rows]
         self.state: Dict[str, object] = {}
         self.eng: Optional[CddpmEngine] = None
         self.grad_scale = 1.0
@@ -316,6 +330,11 @@ class UNetTrainer:
         ec = self.linear(l1, "label_emb.2", silu_in=True)
         emb = torch.cat([et, ec], dim=1).contiguous()
         sv.update(temb=temb, y1=y1, l1=l1, cond=cond, emb=emb, x=x)
+        film_all = None
+        if self.emb_rows:           # FiLM (scale | shift) of all ResBlocks: one [B, E] x [E, 11776] product
+            film_all = self._new(B, self.emb_rows)
+            self._ck(self.lib.cddpm_op_linear(self.h, _p(emb), _p(self.emb_w), _p(self.emb_b), B, self.emb_rows, emb.shape[1], 1, _p(film_all),
+                                              self._s()), "op_linear")
         hs: List[torch.Tensor] = []
         cur = None
         for kind, name, a in self.program:
@@ -326,7 +345,11 @@ class UNetTrainer:
                 hs.append(cur)
             elif kind == "res":
                 x1 = hs.pop() if a.get("concat") else None
-                film = self.linear(emb, name + ".emb_layers.1", silu_in=True)
+                if film_all is not None:
+                    o, n2 = self.emb_off[name], 2 * a["cout"]
+                    film = film_all[:, o:o + n2].contiguous()
+                else:
+                    film = self.linear(emb, name + ".emb_layers.1", silu_in=True)
                 r = dict(x0=cur, x1=x1, film=film, rec_in=self.rec_of(cur, x1))
                 coef1 = self.gn_coef(cur, x1, name + ".in_layers.0")
                 r["coef1"] = coef1
@@ -384,6 +407,7 @@ class UNetTrainer:
         B, _c, H, W = dout.shape
         dout = dout.contiguous().float()
         demb = torch.zeros_like(sv["emb"])
+        dfilm_all = self._new(B, self.emb_rows) if self.emb_rows else None
         skip_grads: List[torch.Tensor] = []      # gradients of popped skip tensors, consumed when the pushing op is reached (reverse order)
         d = None
         for kind, name, a in reversed(self.program):
@@ -421,7 +445,10 @@ class UNetTrainer:
                     dxs = self.dgrad(name + ".skip_connection", d)            # [B,H,W,Cin] over the concatenation
                     self.wgrad(name + ".skip_connection", x0, x1, None, False, d)
                 dh1, dfilm = self.gn_bwd(h1, da2, name + ".out_layers.0", film, rec=r["rec_h1"])
-                self.add_(demb, self.linear_bwd(sv["emb"], name + ".emb_layers.1", dfilm, True))       # film = Linear(SiLU(emb))
+                if dfilm_all is not None:
+                    dfilm_all[:, self.emb_off[name]:self.emb_off[name] + dfilm.shape[1]].copy_(dfilm)     # one backward for all blocks below
+                else:
+                    self.add_(demb, self.linear_bwd(sv["emb"], name + ".emb_layers.1", dfilm, True))       # film = Linear(SiLU(emb))
                 if a["kind"] == "down":
                     dhp = self.dgrad(c1, dh1)
                     self.wgrad(c1, r["hp"], None, None, False, dh1)
@@ -451,6 +478,10 @@ class UNetTrainer:
                          "op_chan_image_corr")
                 self._ck(self.lib.cddpm_op_bias_grad(self.h, _p(d), B * H * W, self.C, _p(g[name + ".bias"]), self._s()), "op_bias_grad")
         assert not skip_grads
+        if dfilm_all is not None:       # film_all = Linear(SiLU(emb)): dW / db of all 27 emb_layers (contiguous in the gradient buffer) and demb
+            emb = sv["emb"]
+            self._ck(self.lib.cddpm_op_linear_backward(self.h, _p(emb), _p(self.emb_w), _p(dfilm_all), B, self.emb_rows, emb.shape[1], 1,
+                                                       _p(self.emb_gw), _p(self.emb_gb), _p(demb), self._s()), "op_linear_backward")
         # embedding MLPs (OpenAI_Unet.py:598-602, :583-590)
         hw = sv["emb"].shape[1] // 2
         det, dec = demb[:, :hw].contiguous(), demb[:, hw:].contiguous()
