@@ -243,8 +243,10 @@ int cddpm_op_gn_coef(cddpm_handle h, const float* src0_dev, int C0, const float*
 size_t cddpm_packed_conv_bytes(int Cout, int Cin, int taps);
 int cddpm_pack_conv_weights(const float* w_host, int Cout, int Cin, int taps, void* dst_host, int* scale_exp_out);
 
-/* ---- first pieces of the training step (csrc/train_kernels.hip). Kernel-level entry points only:
- *      the step itself (src/models/DDPM_2D.py:114-135 -> cond_DDPM.py:565-645 with gradients, Adam, gradient all-reduce) is not built. */
+/* ---- the training step (csrc/train_kernels.hip, csrc/encoder_train.hip): the operators that the host
+ *      sequencing of the package (training.py, encoder_training.py) strings into src/models/DDPM_2D.py:114-135 -> cond_DDPM.py:565-645
+ *      with gradients, Adam (:305-306) and the gradient all-reduce. Host-pointer variants (w_host ...) serve the kernel tests; the step
+ *      itself runs on the device-resident calls further down (cddpm_op_pack_conv, cddpm_op_conv_packed, scratch arena). */
 /* dL/d(input) of Conv2d(k in {1,3}, padding k/2): dx[B,H,W,Cin] = conv_k(dy[B,H,W,Cout], w transposed in (Cout,Cin) and flipped in
  * (ky,kx)) -- the fused forward convolution kernel on host-repacked weights. w_host is the FORWARD weight [Cout,Cin,k,k];
  * Cin must be a multiple of 128 and Cout of 32 (true for every convolution inside the UNet). */
@@ -253,8 +255,10 @@ int cddpm_op_conv_dgrad(cddpm_handle h, const float* dy_dev, int Cout, const flo
 /* dL/d(weight), dL/d(bias) of y = Conv2d(k in {1,3}, padding k/2) applied to a = act(cat[x0, x1]) with act(v) = silu?((v - mean) *
  * a + d) as in cddpm_op_conv (coef_dev [3][B][C0 + C1] or NULL): dw_dev [Cout,Cin,k,k] (PyTorch layout) = sum over batch and pixels of
  * dy (x) a, db_dev [Cout] = sum of dy (may be NULL). x0_dev [B,H,W,C0], x1_dev [B,H,W,C1] or NULL (C1 = 0), dy_dev [B,H,W,Cout];
- * C0 + C1 a multiple of 32 (k = 3) or 64 (k = 1), C0 a multiple of 64 when C1 > 0, Cout of 64, H of 4. upsample != 0: the conv
- * input is the nearest x2 upsampling of act(x0) (up ResBlocks, OpenAI_Unet.py:289-293): x0_dev is [B,H/2,W/2,C0], H and W even. */
+ * C0 + C1 a multiple of 32, C0 of 32 when C1 > 0, Cout of 64 (the CDDPM_WGRAD=f32 family: 64 for k = 1, C0 of 64, H of 4). upsample != 0:
+ * the conv input is the nearest x2 upsampling of act(x0) (up ResBlocks, OpenAI_Unet.py:289-293): x0_dev is [B,H/2,W/2,C0], H and W even.
+ * Arithmetic (environment CDDPM_WGRAD): h3 (default) products from two-term fp16 splits of both operands on v_mfma_f32_16x16x32_f16,
+ * fp32 accumulation -- the forward kernel's arithmetic; h1 plain fp16 operands; f32 v_mfma_f32_32x32x2_f32. */
 int cddpm_op_conv_wgrad(cddpm_handle h, const float* x0_dev, int C0, const float* x1_dev, int C1, const float* coef_dev, int silu,
                         int upsample, const float* dy_dev, int Cout, int ksize, float* dw_dev, float* db_dev, int B, int H, int W,
                         void* stream);
