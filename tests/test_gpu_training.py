@@ -107,3 +107,43 @@ def test_training_steps_reduce_the_loss(synth, sd_np):
     losses = [float(tr.training_step(trainer, x01.to(dev), cond.to(dev), t=t.to(dev), noise=noise.to(dev), lr=1e-4)) for _ in range(4)]
     print("losses", losses)
     assert all(np.isfinite(losses)) and losses[-1] < losses[0]
+
+
+def test_three_optimisation_steps_track_float64_training(oracle, synth, sd_np):
+    """BASELINE config 5 end to end at small size: three complete optimisation steps (q_sample, UNet forward, noise-prediction MSE, backward,
+    Adam lr 1e-4, device re-packing of the updated weights) against the same three steps done by float64 autograd through the oracle +
+    torch.optim.Adam: the loss of every step and the parameters after the third. Adam's first steps move every parameter by ~lr * sign(g),
+    so a parameter whose gradient is within rounding of zero may legitimately go the other way (2 lr per step): the maximum deviation is
+    bounded by that, the mean deviation has to be far below it."""
+    tr = load_pkg("training")
+    T, B, H, W, lr, steps = 1000, 2, 32, 32, 1e-4, 3
+    dev = torch.device("cuda", 0)
+    buf64 = oracle.to_float64(oracle.schedule_buffers(T))
+    sd = {k: torch.nn.Parameter(torch.from_numpy(v).double()) for k, v in sd_np.items()}
+    opt = torch.optim.Adam(list(sd.values()), lr=lr)
+    trainer = tr.UNetTrainer({k: torch.from_numpy(v) for k, v in sd_np.items()}, device=dev)
+    ref_losses, got_losses = [], []
+    for s in range(steps):
+        x01, cond, noise, t = _inputs(synth, B, H, W, T, 11 + s)
+        x0 = x01.double() * 2 - 1
+        out = oracle.unet_forward(oracle.q_sample(x0, t, noise.double(), buf64), t, cond.double(), sd)
+        loss = _loss_of(out, noise.double(), buf64["p2_loss_weight"][t], "l2")
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        ref_losses.append(float(loss))
+        got_losses.append(float(tr.training_step(trainer, x01.to(dev), cond.to(dev), t=t.to(dev), noise=noise.to(dev), timesteps=T,
+                                                 objective="pred_noise", loss_type="l2", lr=lr)))
+    print("losses float64:", ref_losses, "HIP:", got_losses)
+    for a, b in zip(ref_losses, got_losses):
+        assert abs(a - b) < 2e-5 * max(1.0, abs(a)), (ref_losses, got_losses)
+    worst, mean_dev, moved = 0.0, [], []
+    for k, v in sd.items():
+        d = (trainer.p[k].double().cpu() - v.detach()).abs()
+        worst = max(worst, float(d.max()))
+        mean_dev.append(float(d.mean()))
+        moved.append(float((v.detach() - torch.from_numpy(sd_np[k]).double()).abs().mean()))
+    print(f"after {steps} steps: max parameter deviation {worst:.2e} (bound {2 * lr * steps:.1e}), mean deviation {np.mean(mean_dev):.2e}, "
+          f"mean parameter movement {np.mean(moved):.2e}")
+    assert worst <= 2.05 * lr * steps
+    assert np.mean(mean_dev) < 0.02 * np.mean(moved)
