@@ -1645,11 +1645,18 @@ int cddpm_op_attention_backward(cddpm_handle h, const float* qkv_dev, const floa
     if (!qkv_dev || !da_dev || !dqkv_dev) return fail(h, "cddpm_op_attention_backward: NULL argument");
     hipStream_t s = (hipStream_t)stream;
     HIPCHECK(h, hipSetDevice(h->device));
-    const size_t nn = (size_t)B * (C / 64) * N * N;
+    static const bool gemm_form = [] { const char* e = getenv("CDDPM_ATTN_BWD"); return e && !strcmp(e, "gemm"); }();
     OpScratch sc(h, s);
-    float *p = sc.n<float>(nn), *dp = sc.n<float>(nn);
-    SCRATCH_CHECK(sc)
-    launch_attention_backward(qkv_dev, da_dev, dqkv_dev, p, dp, B, N, C, s);
+    if (gemm_form) {
+        const size_t nn = (size_t)B * (C / 64) * N * N;
+        float *p = sc.n<float>(nn), *dp = sc.n<float>(nn);
+        SCRATCH_CHECK(sc)
+        launch_attention_backward(qkv_dev, da_dev, dqkv_dev, p, dp, B, N, C, s);
+    } else {
+        float* stats = sc.n<float>((size_t)B * (C / 64) * N * 2);
+        SCRATCH_CHECK(sc)
+        launch_attention_backward_flash(qkv_dev, da_dev, dqkv_dev, stats, B, N, C, s);
+    }
     HIPCHECK(h, hipGetLastError());
     return 0;
 }
@@ -1661,7 +1668,8 @@ int cddpm_op_linear_backward(cddpm_handle h, const float* x_dev, const float* w_
     hipStream_t s = (hipStream_t)stream;
     HIPCHECK(h, hipSetDevice(h->device));
     OpScratch sc(h, s);
-    float* a = silu_in ? sc.n<float>((size_t)M * K) : nullptr;
+    const size_t nscr = linear_backward_scratch_floats(M, N, K, silu_in);
+    float* a = nscr ? sc.n<float>(nscr) : nullptr;
     SCRATCH_CHECK(sc)
     launch_linear_backward(x_dev, w_dev, dy_dev, M, N, K, silu_in, a, dw_dev, db_dev, dx_dev, s);
     HIPCHECK(h, hipGetLastError());

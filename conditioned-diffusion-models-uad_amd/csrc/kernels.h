@@ -164,10 +164,13 @@ void launch_conv_wgrad(const float* x0, int C0, const float* x1, int C1, const f
                        int W, int Cout, int taps, float* part, int P, void* images, float* dw, float* db, hipStream_t stream);
 void launch_bias_grad(const float* dy, long long npix, int C, float* db, double* scratch /* 512 * C doubles */, hipStream_t stream);
 // QKVAttention backward: qkv [B][N][3C] (q | k | v), da [B][N][C] -> dqkv [B][N][3C]; p, dp: scratch [B * C / 64][N][N] floats each
+// flash-style (default): stats = B * heads * N * 2 floats of scratch; the GEMM form below (CDDPM_ATTN_BWD=gemm) materialises p, dp [B heads][N][N]
+void launch_attention_backward_flash(const float* qkv, const float* da, float* dqkv, float* stats, int B, int N, int C, hipStream_t stream);
 void launch_attention_backward(const float* qkv, const float* da, float* dqkv, float* p, float* dp, int B, int N, int C,
                                hipStream_t stream);
 // backward of y = [SiLU](x) W^T + b: x [M][K], W [N][K], dy [M][N] -> dW [N][K], db [N] (or nullptr), dx [M][K] (or nullptr);
 // a_scratch [M][K] when silu_in
+size_t linear_backward_scratch_floats(int M, int N, int K, int silu_in);      // floats of a_scratch
 void launch_linear_backward(const float* x, const float* W, const float* dy, int M, int N, int K, int silu_in, float* a_scratch,
                             float* dW, float* db, float* dx, hipStream_t stream);
 void launch_unpool2(const float* dyp, float* dx, int B, int H, int W, int C, float scale, int accumulate, hipStream_t stream);

@@ -1031,6 +1031,51 @@ __global__ void colsum_kernel(const float* __restrict__ dy, int M, int N, float*
     db[n] = (float)s;
 }
 
+// dx [M][K] = dy [M][N] . W [N][K] for a SKINNY M (the embedding MLPs: M = batch): the 64 x 64-tile GEMM would walk N serially in K / 64
+// workgroups (16 workgroups x 368 steps for the 27 emb_layers as one [11776][1024] matrix). Here: workgroup = (64 columns of K, one of
+// LIN_NSPLIT ranges of N), thread = (column, quarter of the M rows); dy of the range sits in LDS (broadcast reads), W rows are read
+// once, coalesced; the partial sums are folded in the order of the ranges.
+constexpr int LIN_NSPLIT = 32;
+__global__ __launch_bounds__(256) void skinny_dx_partial_kernel(const float* __restrict__ dy, const float* __restrict__ W, int M, int N, int K,
+                                                                float* __restrict__ part /*[LIN_NSPLIT][M][K]*/) {
+    __shared__ float dys[64][65];                 // [m][n within the 64-row step]
+    const int tid = threadIdx.x, kc = blockIdx.x * 64 + (tid & 63), mg = tid >> 6;
+    const int per = (N + LIN_NSPLIT - 1) / LIN_NSPLIT, n0 = blockIdx.y * per, n1 = min(N, n0 + per);
+    const int mq = (M + 3) / 4, m0 = mg * mq;     // this thread's rows [m0, m0 + mq), mq <= 16
+    float acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    for (int ns = n0; ns < n1; ns += 64) {
+        __syncthreads();
+        for (int e = tid; e < M * 64; e += 256) {
+            const int m = e >> 6, nn = e & 63;
+            dys[m][nn] = (ns + nn < n1) ? dy[(size_t)m * N + ns + nn] : 0.f;
+        }
+        __syncthreads();
+        const int lim = min(64, n1 - ns);
+        for (int nn = 0; nn < lim; ++nn) {
+            const float w = (kc < K) ? W[(size_t)(ns + nn) * K + kc] : 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                if (i < mq && m0 + i < M) acc[i] = fmaf(dys[m0 + i][nn], w, acc[i]);
+        }
+    }
+    if (kc < K)
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            if (i < mq && m0 + i < M) part[((size_t)blockIdx.y * M + m0 + i) * K + kc] = acc[i];
+}
+__global__ __launch_bounds__(256) void skinny_dx_fold_kernel(const float* __restrict__ part, int M, int K, float* __restrict__ dx) {
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (long long)M * K) return;
+    float sum = 0.f;
+    for (int sp = 0; sp < LIN_NSPLIT; ++sp) sum += part[(size_t)sp * M * K + e];
+    dx[e] = sum;
+}
+size_t linear_backward_scratch_floats(int M, int N, int K, int silu_in) {
+    return (size_t)(silu_in ? M * (size_t)K : 0) + ((M <= 64 && N >= 1024) ? (size_t)LIN_NSPLIT * M * K : 0);
+}
+
 void launch_linear_backward(const float* x, const float* W, const float* dy, int M, int N, int K, int silu_in, float* a_scratch,
                             float* dW, float* db, float* dx, hipStream_t stream) {
     const float* act = x;
@@ -1047,8 +1092,14 @@ void launch_linear_backward(const float* x, const float* W, const float* dy, int
     if (db) hipLaunchKernelGGL(colsum_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, dy, M, N, db);
     if (dx) {
         // dx [M][K] = dy [M][N] . W [N][K]
-        g.A = dy; g.lda = N; g.transA = 0; g.B = W; g.ldb = K; g.transB = 0; g.C = dx; g.ldc = K; g.M = M; g.N = K; g.K = N;
-        launch_gemm_f32(g, 1, stream);
+        if (M <= 64 && N >= 1024) {
+            float* part = a_scratch + (silu_in ? (size_t)M * K : 0);
+            hipLaunchKernelGGL(skinny_dx_partial_kernel, dim3((K + 63) / 64, LIN_NSPLIT), dim3(256), 0, stream, dy, W, M, N, K, part);
+            hipLaunchKernelGGL(skinny_dx_fold_kernel, dim3((unsigned)(((long long)M * K + 255) / 256)), dim3(256), 0, stream, part, M, K, dx);
+        } else {
+            g.A = dy; g.lda = N; g.transA = 0; g.B = W; g.ldb = K; g.transB = 0; g.C = dx; g.ldc = K; g.M = M; g.N = K; g.K = N;
+            launch_gemm_f32(g, 1, stream);
+        }
         if (silu_in) {
             const long long n = (long long)M * K;
             hipLaunchKernelGGL(silu_bwd_mul_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, x, dx, n);
