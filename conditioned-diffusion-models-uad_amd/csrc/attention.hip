@@ -419,34 +419,32 @@ __global__ __launch_bounds__(256, 2) void attention_bwd_kv_kernel(const float* _
             ldsD[tid] = ok ? st[(size_t)(q0 + tid) * 2 + 1] : 0.f;
         }
         __syncthreads();
-        // S[query][key] = (Q/8) . K^T and dP[query][key] = dA . V^T: queries in the accumulator registers, the key on the lane
-        f32x16 S[2], dP[2];
-#pragma unroll
+        // S[query][key] = (Q/8) . K^T and dP[query][key] = dA . V^T: queries in the accumulator registers, the key on the lane;
+        // one 32-query sub-tile at a time (32 instead of 64 live accumulator registers for S and dP: no spills)
+#pragma unroll 1
         for (int qt = 0; qt < 2; ++qt) {
+            f32x16 S, dP;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { S[qt][r] = 0.f; dP[qt][r] = 0.f; }
+            for (int r = 0; r < 16; ++r) { S[r] = 0.f; dP[r] = 0.f; }
             const int row = 32 * qt + li;
 #pragma unroll
             for (int g = 0; g < 8; ++g) {
                 const float4 qf = ldsQ4[row * 16 + ((2 * g + lh) ^ (row & 15))];
                 const float4 af = ldsA4[row * 16 + ((2 * g + lh) ^ (row & 15))];
-                S[qt] = __builtin_amdgcn_mfma_f32_32x32x2f32(qf.x, kreg[g].x, S[qt], 0, 0, 0);
-                S[qt] = __builtin_amdgcn_mfma_f32_32x32x2f32(qf.y, kreg[g].y, S[qt], 0, 0, 0);
-                S[qt] = __builtin_amdgcn_mfma_f32_32x32x2f32(qf.z, kreg[g].z, S[qt], 0, 0, 0);
-                S[qt] = __builtin_amdgcn_mfma_f32_32x32x2f32(qf.w, kreg[g].w, S[qt], 0, 0, 0);
-                dP[qt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.x, vreg[g].x, dP[qt], 0, 0, 0);
-                dP[qt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.y, vreg[g].y, dP[qt], 0, 0, 0);
-                dP[qt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.z, vreg[g].z, dP[qt], 0, 0, 0);
-                dP[qt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.w, vreg[g].w, dP[qt], 0, 0, 0);
+                S = __builtin_amdgcn_mfma_f32_32x32x2f32(qf.x, kreg[g].x, S, 0, 0, 0);
+                S = __builtin_amdgcn_mfma_f32_32x32x2f32(qf.y, kreg[g].y, S, 0, 0, 0);
+                S = __builtin_amdgcn_mfma_f32_32x32x2f32(qf.z, kreg[g].z, S, 0, 0, 0);
+                S = __builtin_amdgcn_mfma_f32_32x32x2f32(qf.w, kreg[g].w, S, 0, 0, 0);
+                dP = __builtin_amdgcn_mfma_f32_32x32x2f32(af.x, vreg[g].x, dP, 0, 0, 0);
+                dP = __builtin_amdgcn_mfma_f32_32x32x2f32(af.y, vreg[g].y, dP, 0, 0, 0);
+                dP = __builtin_amdgcn_mfma_f32_32x32x2f32(af.z, vreg[g].z, dP, 0, 0, 0);
+                dP = __builtin_amdgcn_mfma_f32_32x32x2f32(af.w, vreg[g].w, dP, 0, 0, 0);
             }
-        }
-#pragma unroll
-        for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int qq = 32 * qt + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                const float pv = __expf(S[qt][r] - ldsL[qq]);
-                const float ds = pv * (dP[qt][r] - ldsD[qq]);
+                const float pv = __expf(S[r] - ldsL[qq]);
+                const float ds = pv * (dP[r] - ldsD[qq]);
                 const float a0 = ldsAp[qq * 64 + li], a1 = ldsAp[qq * 64 + 32 + li];
                 const float x0 = ldsQp[qq * 64 + li], x1 = ldsQp[qq * 64 + 32 + li];
                 dV[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, pv, dV[0], 0, 0, 0);
@@ -454,6 +452,7 @@ __global__ __launch_bounds__(256, 2) void attention_bwd_kv_kernel(const float* _
                 dK[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0, ds, dK[0], 0, 0, 0);
                 dK[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1, ds, dK[1], 0, 0, 0);
             }
+        }
     }
     if (keyi < N) {
         float* krow_o = dqkv + ((size_t)b * N + keyi) * C3 + C + hd * 64;
