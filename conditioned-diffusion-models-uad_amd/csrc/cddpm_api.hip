@@ -1844,7 +1844,8 @@ int cddpm_op_enc_avgpool(cddpm_handle h, const float* x_dev, float* g_dev, int B
 
 int cddpm_op_gn_silu_backward(cddpm_handle h, const float* x_dev, const float* da_dev, const float* gamma_host,
                               const float* beta_host, const float* film_dev, int silu, float* dx_dev, float* dgamma_dev,
-                              float* dbeta_dev, float* dfilm_dev, const float* rec_dev, int nrec, int B, int HW, int C, void* stream) {
+                              float* dbeta_dev, float* dfilm_dev, const float* rec_dev, int nrec, const float* add_dev, int B, int HW, int C,
+                              void* stream) {
     if (!h) return -1;
     if (C % 32 || C <= 0 || C > 1024 || B < 1 || HW < 1 || (rec_dev && nrec < 1))
         return fail(h, "cddpm_op_gn_silu_backward: unsupported shape (C %d)", C);
@@ -1864,7 +1865,7 @@ int cddpm_op_gn_silu_backward(cddpm_handle h, const float* x_dev, const float* d
     if (!rec_dev) launch_gn_partial(x_dev, C, B, HW, ns, rec, s);      // statistics records of x: given (kept from the forward pass) or swept here
     launch_gn_bwd_planes(rec_dev ? rec_dev : rec, rec_dev ? nrec : ns, g, bt, film_dev, B, C, HW, planes, s);
     launch_gn_silu_backward(x_dev, da_dev, planes, g, bt, film_dev, silu, B, C, HW, ns, part, out_bc, dx_dev, dgamma_dev, dbeta_dev,
-                            dfilm_dev, s);
+                            dfilm_dev, add_dev, s);
     HIPCHECK(h, hipGetLastError());
     return 0;
 }

@@ -186,7 +186,7 @@ void launch_adam(float* p, const float* g, float* m, float* v, long long n, floa
                  hipStream_t stream);
 void launch_gn_silu_backward(const float* x, const float* da, const float* planes, const float* gamma, const float* beta,
                              const float* film, int silu, int B, int C, int HW, int nsplit, double* part, float* out_bc, float* dx,
-                             float* dgamma, float* dbeta, float* dfilm, hipStream_t stream);
+                             float* dgamma, float* dbeta, float* dfilm, const float* add /* dx += add, or nullptr */, hipStream_t stream);
 
 // ------------------------------------------------------------------------------------------------
 // attention core (attention.hip): qkv NHWC [B,N,3C] -> out [B,N,C], heads of 64 channels

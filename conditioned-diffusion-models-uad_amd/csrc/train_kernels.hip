@@ -16,8 +16,8 @@
 //   Two passes over (x, da): gn_bwd_partial_kernel (per-channel S1, S2 over pixel splits, fp64 inside) and gn_bwd_apply_kernel
 //   (elementwise dx), with gn_bwd_finalize_kernel (tiny) in between. The statistics (mu, r) are an input: the forward's.
 // * conv wgrad (below): a pixel-contraction GEMM on the fp32 MFMA with the activation recomputed while staging.
-// Not here yet: attention backward, the one-channel input / output convolutions, the embedding MLPs, the
-// up/down-sampling variants, Adam, the gradient all-reduce, the step's orchestration.
+// Further down: the weight-gradient families, the batched fp32 GEMM and the linear backward, resampling backward, the one-channel
+// convolutions' gradients, the loss, Adam. (Attention backward: attention.hip; the encoder: encoder_train.hip; sequencing: training.py.)
 #include "kernels.h"
 #include <cstdlib>
 #include <cstring>
@@ -141,7 +141,8 @@ __global__ void gn_bwd_param_kernel(const float* __restrict__ out_bc, const floa
 
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ da,
                                                            const float* __restrict__ planes, const float* __restrict__ out_bc,
-                                                           int B, int C, int HW, int silu, float* __restrict__ dx) {
+                                                           int B, int C, int HW, int silu, const float* __restrict__ add,
+                                                           float* __restrict__ dx) {
     const int ncq = C >> 2;
     const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
     if (e >= (long long)B * HW * ncq) return;
@@ -158,6 +159,10 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
                        o.f = rs.f * (du * gp.f - m1.f - xh * m2.f); }
     CDDPM_GNB(x) CDDPM_GNB(y) CDDPM_GNB(z) CDDPM_GNB(w)
 #undef CDDPM_GNB
+    if (add) {      // the gradient arriving through the block's skip path (identity or 1x1 skip_connection): saves a separate pass
+        const float4 av = *reinterpret_cast<const float4*>(add + off);
+        o.x += av.x; o.y += av.y; o.z += av.z; o.w += av.w;
+    }
     *reinterpret_cast<float4*>(dx + off) = o;
 }
 
@@ -214,13 +219,13 @@ void launch_gn_bwd_planes(const float* rec, int nrec, const float* gamma, const 
 
 void launch_gn_silu_backward(const float* x, const float* da, const float* planes, const float* gamma, const float* beta,
                              const float* film, int silu, int B, int C, int HW, int nsplit, double* part, float* out_bc, float* dx,
-                             float* dgamma, float* dbeta, float* dfilm, hipStream_t stream) {
+                             float* dgamma, float* dbeta, float* dfilm, const float* add, hipStream_t stream) {
     hipLaunchKernelGGL(gn_bwd_partial_kernel, dim3(nsplit, B), dim3(256), 0, stream, x, da, planes, B, C, HW, nsplit, silu, part);
     hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(B), dim3(256), 0, stream, part, planes, gamma, beta, B, C, HW, nsplit, out_bc, dfilm);
     hipLaunchKernelGGL(gn_bwd_param_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, out_bc, film, B, C, dgamma, dbeta);
     const long long total = (long long)B * HW * (C / 4);
     hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, x, da, planes, out_bc, B, C, HW,
-                       silu, dx);
+                       silu, add, dx);
 }
 
 // ------------------------------------------------------------------------------------------------------------------

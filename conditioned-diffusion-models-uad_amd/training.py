@@ -237,15 +237,15 @@ class UNetTrainer:
                                                _p(coef), B, HW, self._s()), "op_gn_coef")
         return coef
 
-    def gn_bwd(self, x, da, name, film=None, silu=True, rec=None):
+    def gn_bwd(self, x, da, name, film=None, silu=True, rec=None, add=None):
         """backward of act(GroupNorm32(x) (1 + scale) + shift): dgamma / dbeta go to the gradient buffer; -> (dx, dfilm or None).
-        rec: x's statistics records kept from the forward pass (else they are swept again)"""
+        rec: x's statistics records kept from the forward pass (else they are swept again); add: a tensor added to dx (skip-path gradient)"""
         B, H, W, Cc = x.shape
         dx = torch.empty_like(x)
         dfilm = self._new(B, 2 * Cc) if film is not None else None
         self._ck(self.lib.cddpm_op_gn_silu_backward(self.h, _p(x), _p(da), _p(self.p[name + ".weight"]), _p(self.p[name + ".bias"]), _p(film),
                                                     int(bool(silu)), _p(dx), _p(self.g[name + ".weight"]), _p(self.g[name + ".bias"]), _p(dfilm),
-                                                    _p(rec), rec.shape[1] if rec is not None else 0, B, H * W, Cc, self._s()),
+                                                    _p(rec), rec.shape[1] if rec is not None else 0, _p(add), B, H * W, Cc, self._s()),
                  "op_gn_silu_backward")
         return dx, dfilm
 
@@ -429,8 +429,7 @@ class UNetTrainer:
                          "op_attention_backward")
                 dn = self.dgrad(name + ".qkv", dqkv)
                 self.wgrad(name + ".qkv", r["x"], None, r["coefn"], False, dqkv)
-                dx, _ = self.gn_bwd(r["x"], dn, name + ".norm", None, False, rec=r["rec"])
-                d = self.add_(dx, d)
+                d, _ = self.gn_bwd(r["x"], dn, name + ".norm", None, False, rec=r["rec"], add=d)       # + the residual path x + h
             elif kind == "res":
                 if a.get("push"):        # this op's output also fed a skip connection: add that gradient
                     d = self.add_(d, skip_grads.pop())
@@ -464,8 +463,8 @@ class UNetTrainer:
                 else:
                     da1 = self.dgrad(c1, dh1)
                     self.wgrad(c1, x0, x1, r["coef1"], True, dh1)
-                    dx, _ = self.gn_bwd(r["xin"] if x1 is not None else x0, da1, name + ".in_layers.0", rec=r["rec_in"])
-                    self.add_(dx, dxs if dxs is not None else d)              # 1x1 skip_connection, or the identity skip
+                    dx, _ = self.gn_bwd(r["xin"] if x1 is not None else x0, da1, name + ".in_layers.0", rec=r["rec_in"],
+                                        add=dxs if dxs is not None else d)        # + the 1x1 skip_connection's gradient, or the identity skip's
                 if x1 is not None:       # split the gradient of the concatenation: [h | popped skip tensor]
                     c0 = x0.shape[-1]
                     skip_grads.append(dx[..., c0:].contiguous())

@@ -371,7 +371,8 @@ int cddpm_op_enc_avgpool(cddpm_handle h, const float* x_dev, float* g_dev, int B
 int cddpm_op_gn_silu_backward(cddpm_handle h, const float* x_dev, const float* da_dev, const float* gamma_host,
                               const float* beta_host, const float* film_dev, int silu, float* dx_dev, float* dgamma_dev,
                               float* dbeta_dev, float* dfilm_dev, const float* rec_dev /* x's statistics records or NULL */, int nrec,
-                              int B, int HW, int C, void* stream);
+                              const float* add_dev /* [B,HW,C] added to dx (the gradient of a parallel skip path), or NULL */, int B, int HW, int C,
+                              void* stream);
 
 /* GroupNorm statistics record counts per sample for an H x W tensor (host arithmetic, callable without a GPU):
  * kind 0 = records the fused convolution's epilogue writes, 1 = the folded-upsample convolution's, 2 = the stand-alone
