@@ -7,9 +7,11 @@ operators of libcddpm_hip.so through their C-ABI entry points (include/cddpm.h, 
 and of the backward runs in csrc/*.hip; torch is used for device memory, views, torch.cat of saved tensors and torch.distributed
 (the gradient all-reduce). fp32 throughout (the gradients carry fp32 accuracy and are checked against autograd on the oracle).
 
-State of this round: UNet forward / backward / Adam are complete for the reference's conditioned configuration and checked against
-autograd (tests/test_gpu_training.py). Not done: the per-call host re-packing of the convolution weights (a step at 128x128 is
-dominated by it: the packers of cddpm_op_conv* run on the CPU), bf16 autocast (BASELINE config 5), the encoder's backward.
+State: device-resident (flat parameter / gradient / Adam buffers, weight images re-packed on the device after every update, operator
+temporaries from one scratch arena, no synchronisation inside a step); loss and all gradients checked against float64 autograd through the
+oracle, three complete steps against float64 autograd + torch Adam (tests/test_gpu_training.py); the context encoder is trained jointly by
+encoder_training.EncoderTrainer. Convolutions keep the inference path's fp32-grade arithmetic (fp16 two-term splits); a plain-fp16
+("precision 16") forward is not offered. Measured: DESIGN.md section 4b.
 """
 from __future__ import annotations
 
