@@ -1,6 +1,9 @@
-"""GPU: first kernel-level pieces of the training step (csrc/train_kernels.hip) against torch autograd
-in float64 on the same seeded inputs: conv dgrad (the fused forward convolution on transposed / flipped weights) and the
-GroupNorm32 / FiLM / SiLU backward. The training STEP (src/models/DDPM_2D.py:114-135) is not built: these are its first bricks."""
+"""GPU: the operators of the training step (csrc/train_kernels.hip, attention.hip) one by one against torch
+autograd in float64 on the same seeded inputs: convolution input / weight gradients, GroupNorm32 / FiLM / SiLU backward, attention and
+linear backward, the device weight packer, resampling backward, the one-channel convolutions' gradients, the loss. The step itself
+(src/models/DDPM_2D.py:114-135): tests/test_gpu_training.py."""
+import ctypes as C
+
 import numpy as np
 import pytest
 import torch
@@ -176,3 +179,83 @@ def test_conv_wgrad_batch_groups_and_ragged_tiles(eng, B, C0, Cout, k, H, W, up)
     eb = float((db.double().cpu() - bias.grad).abs().max() / bias.grad.abs().max())
     print(B, C0, Cout, k, H, W, up, f"dW rel {ew:.2e}  db rel {eb:.2e}")
     assert ew < 1e-5 and eb < 1e-5
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def test_resampling_backward_ops(eng):
+    """AvgPool2d(2) backward (cddpm_op_unpool2, scale 1/4) and nearest x2 upsample backward (cddpm_op_sumpool2), plain and accumulating"""
+    torch.manual_seed(1)
+    B, Cc, H, W = 2, 64, 6, 10
+    x = torch.randn(B, Cc, H, W, dtype=torch.float64, requires_grad=True)
+    dyp = torch.randn(B, Cc, H // 2, W // 2, dtype=torch.float64)
+    F.avg_pool2d(x, 2).backward(dyp)
+    out = torch.empty(B, H, W, Cc, device="cuda")
+    assert eng.lib.cddpm_op_unpool2(eng._h, nhwc(dyp).data_ptr(), out.data_ptr(), B, H, W, Cc, C.c_float(0.25), 0, None) == 0
+    base = torch.randn(B, H, W, Cc, device="cuda")
+    acc = base.clone()
+    assert eng.lib.cddpm_op_unpool2(eng._h, nhwc(dyp).data_ptr(), acc.data_ptr(), B, H, W, Cc, C.c_float(0.25), 1, None) == 0
+    torch.cuda.synchronize()
+    assert float((nchw(out).double() - x.grad).abs().max()) < 1e-6
+    assert float((acc - base - out).abs().max()) < 1e-6
+    xs = torch.randn(B, Cc, H // 2, W // 2, dtype=torch.float64, requires_grad=True)
+    dy = torch.randn(B, Cc, H, W, dtype=torch.float64)
+    F.interpolate(xs, scale_factor=2, mode="nearest").backward(dy)
+    outp = torch.empty(B, H // 2, W // 2, Cc, device="cuda")
+    assert eng.lib.cddpm_op_sumpool2(eng._h, nhwc(dy).data_ptr(), outp.data_ptr(), B, H, W, Cc, 0, None) == 0
+    torch.cuda.synchronize()
+    assert float((nchw(outp).double() - xs.grad).abs().max()) < 2e-6
+
+
+def test_one_channel_convolution_gradients_and_loss(eng):
+    """the UNet's two one-channel convolutions: head Conv2d(C -> 1) behind GroupNorm + SiLU (input gradient cddpm_op_head_dgrad, weight
+    gradient cddpm_op_chan_image_corr with sign -1) and the input Conv2d(1 -> C) (weight gradient, sign +1; bias cddpm_op_bias_grad);
+    the loss operator (L1 / L2, p2 weights, loss scale)"""
+    torch.manual_seed(2)
+    B, Cc, H, W = 2, 128, 8, 12
+    lib, h = eng.lib, eng._h
+    x = torch.randn(B, Cc, H, W, dtype=torch.float64)
+    coef = torch.stack([torch.randn(B, Cc) * 0.2, 1 + 0.2 * torch.randn(B, Cc), torch.randn(B, Cc) * 0.2]).double()
+    a = F.silu((x - coef[0][:, :, None, None]) * coef[1][:, :, None, None] + coef[2][:, :, None, None]).requires_grad_(True)
+    w = (torch.randn(1, Cc, 3, 3, dtype=torch.float64) / (9 * Cc) ** 0.5).requires_grad_(True)
+    out = F.conv2d(a, w, None, padding=1)
+    dout = torch.randn_like(out)
+    out.backward(dout)
+    w9 = w.detach().float().reshape(Cc, 9).t().contiguous().cuda()
+    doutg = dout.float().cuda().contiguous()
+    dact = torch.empty(B, H, W, Cc, device="cuda")
+    assert lib.cddpm_op_head_dgrad(h, doutg.data_ptr(), w9.data_ptr(), dact.data_ptr(), B, H, W, Cc, None) == 0
+    dw = torch.empty(Cc, 9, device="cuda")
+    assert lib.cddpm_op_chan_image_corr(h, nhwc(x).data_ptr(), coef.float().cuda().contiguous().data_ptr(), 1, doutg.data_ptr(), -1, dw.data_ptr(),
+                                        B, H, W, Cc, None) == 0
+    torch.cuda.synchronize()
+    assert float((nchw(dact).double() - a.grad).abs().max() / a.grad.abs().max()) < 2e-6
+    assert float((dw.cpu().double().reshape(1, Cc, 3, 3) - w.grad).abs().max() / w.grad.abs().max()) < 5e-6
+    # input convolution 1 -> C
+    img = torch.rand(B, 1, H, W, dtype=torch.float64)
+    w_in = (torch.randn(Cc, 1, 3, 3, dtype=torch.float64) / 3).requires_grad_(True)
+    b_in = torch.zeros(Cc, dtype=torch.float64, requires_grad=True)
+    y = F.conv2d(img, w_in, b_in, padding=1)
+    dy = torch.randn_like(y)
+    y.backward(dy)
+    dwi, dbi = torch.empty(Cc, 9, device="cuda"), torch.empty(Cc, device="cuda")
+    assert lib.cddpm_op_chan_image_corr(h, nhwc(dy).data_ptr(), None, 0, img.float().cuda().contiguous().data_ptr(), 1, dwi.data_ptr(), B, H, W, Cc, None) == 0
+    assert lib.cddpm_op_bias_grad(h, nhwc(dy).data_ptr(), B * H * W, Cc, dbi.data_ptr(), None) == 0
+    torch.cuda.synchronize()
+    assert float((dwi.cpu().double().reshape(Cc, 1, 3, 3) - w_in.grad).abs().max() / w_in.grad.abs().max()) < 5e-6
+    assert float((dbi.cpu().double() - b_in.grad).abs().max() / b_in.grad.abs().max()) < 5e-6
+    # loss
+    for l2 in (0, 1):
+        o = torch.randn(B, 1, H, W, dtype=torch.float64, requires_grad=True)
+        tgt, p2w, S = torch.randn(B, 1, H, W, dtype=torch.float64), torch.tensor([0.7, 1.3], dtype=torch.float64), 256.0
+        d = o - tgt
+        per = ((d ** 2) if l2 else d.abs()).reshape(B, -1).mean(dim=1) * p2w
+        per.mean().backward()
+        dog, lb = torch.empty(B, 1, H, W, device="cuda"), torch.empty(B, device="cuda")
+        assert lib.cddpm_op_loss(h, o.detach().float().cuda().data_ptr(), tgt.float().cuda().data_ptr(), p2w.float().cuda().data_ptr(), l2, B, H * W,
+                                 C.c_float(S), dog.data_ptr(), lb.data_ptr(), None) == 0
+        torch.cuda.synchronize()
+        assert float((lb.cpu().double() - per.detach()).abs().max()) < 1e-6
+        assert float((dog.cpu().double() / S - o.grad).abs().max() / o.grad.abs().max()) < 2e-6
