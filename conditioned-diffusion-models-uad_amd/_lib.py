@@ -93,7 +93,7 @@ SYMBOLS = {
     "cddpm_op_head_dgrad": (_i, [_vp, _fp, _fp, _fp, _i, _i, _i, _i, _vp]),
     "cddpm_op_loss": (_i, [_vp, _fp, _fp, _fp, _i, _i, _i, C.c_float, _fp, _fp, _vp]),
     "cddpm_op_adam": (_i, [_vp, _fp, _fp, _fp, _fp, _i64, C.c_float, C.c_float, C.c_float, C.c_float, _i, C.c_float, _vp]),
-    "cddpm_op_gn_silu_backward": (_i, [_vp, _fp, _fp, _fp, _fp, _fp, _i, _fp, _fp, _fp, _fp, _fp, _i, _fp, _i, _i, _i, _vp]),
+    "cddpm_op_gn_silu_backward": (_i, [_vp, _fp, _fp, _i, _fp, _fp, _fp, _fp, _i, _fp, _fp, _fp, _fp, _fp, _fp, _i, _fp, _i, _i, _i, _vp]),
     "cddpm_op_enc_pack_w": (_i, [_vp, _fp, _i, _i, _i, _fp, _fp, _vp]),
     "cddpm_op_enc_conv": (_i, [_vp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "cddpm_op_enc_conv_wgrad": (_i, [_vp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _vp]),
@@ -106,7 +106,7 @@ SYMBOLS = {
     "cddpm_op_set_scratch": (_i, [_vp, _sz]),
     "cddpm_op_absmax": (_i, [_vp, _fp, _i64, _fp, _vp]),
     "cddpm_op_pack_conv": (_i, [_vp, _fp, _i, _i, _i, _i, _i, _vp, _vp]),
-    "cddpm_op_conv_packed": (_i, [_vp, _fp, _i, _fp, _i, _fp, _i, _i, _vp, _i, _fp, _i, _i, _fp, _i, _fp, _i, _vp, _fp, _fp, _i, _i, _i, _vp]),
+    "cddpm_op_conv_packed": (_i, [_vp, _fp, _i, _fp, _i, _fp, _i, _i, _vp, _i, _fp, _i, _i, _fp, _i, _fp, _i, _fp, _i, _vp, _fp, _fp, _i, _i, _i, _vp]),
     "cddpm_op_gn_coef_rec": (_i, [_vp, _fp, _i, _i, _fp, _i, _i, _fp, _fp, _fp, _fp, _i, _i, _vp]),
     "cddpm_stat_records": (_i, [_i, _i, _i]),
     "cddpm_packed_conv_bytes": (_sz, [_i, _i, _i]),

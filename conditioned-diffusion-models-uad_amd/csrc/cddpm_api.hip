@@ -1321,13 +1321,13 @@ int cddpm_op_pack_conv(cddpm_handle h, const float* w_dev, int Cout, int Cin, in
 
 int cddpm_op_conv_packed(cddpm_handle h, const float* src0, int C0, const float* src1, int C1, const float* coef_dev, int silu, int folded_up,
                          const void* packed_dev, int scale_exp, const float* bias_dev, int Cout, int ksize, const float* res_dev,
-                         int res_upsample, const float* skip_dev, int S0, const void* skip_packed_dev, float* out_dev, float* stats_dev, int B,
-                         int H, int W, void* stream) {
+                         int res_upsample, const float* skip_dev, int S0, const float* skip1_dev, int S1, const void* skip_packed_dev,
+                         float* out_dev, float* stats_dev, int B, int H, int W, void* stream) {
     if (!h) return -1;
     const int Cin = C0 + C1;
     if (conv_mode() != 2) return fail(h, "cddpm_op_conv_packed: default convolution family (CDDPM_CONV=h3) only");
     if ((ksize != 1 && ksize != 3) || C0 <= 0 || C0 % 32 || C1 < 0 || C1 % 32 || Cout <= 0 || Cout % 128 || Cout > 4096 || B < 1 || H < 1 || W < 1 ||
-        (folded_up && (ksize != 3 || C1 || H % 2 || W % 2)) || (skip_dev && (S0 <= 0 || S0 % 32 || !skip_packed_dev || ksize != 3)) ||
+        (folded_up && (ksize != 3 || C1 || H % 2 || W % 2)) || (skip_dev && (S0 <= 0 || S0 % 32 || !skip_packed_dev || ksize != 3 || S1 < 0 || S1 % 32 || (S1 > 0 && !skip1_dev))) ||
         (C1 && !src1) || scale_exp < 0 || scale_exp > 24)
         return fail(h, "cddpm_op_conv_packed: unsupported shape (k %d, C0 %d, C1 %d, Cout %d, S0 %d)", ksize, C0, C1, Cout, S0);
     if (!src0 || !packed_dev || !out_dev) return fail(h, "cddpm_op_conv_packed: NULL argument");
@@ -1339,6 +1339,7 @@ int cddpm_op_conv_packed(cddpm_handle h, const float* src0, int C0, const float*
     a.srcH = folded_up ? H / 2 : H; a.srcW = folded_up ? W / 2 : W;
     a.coef = coef_dev; a.silu = silu; a.wpk = static_cast<const float*>(packed_dev); a.bias = bias_dev; a.res = res_dev; a.res_up = res_upsample;
     a.skip0 = skip_dev; a.S0 = skip_dev ? S0 : 0; a.skip_wpk = static_cast<const float*>(skip_packed_dev);
+    a.skip1 = (skip_dev && S1 > 0) ? skip1_dev : nullptr; a.S1 = (skip_dev && S1 > 0) ? S1 : 0;      // the skip input as two concatenated tensors
     a.wscale_inv = ldexpf(1.0f, -scale_exp);
     a.out = out_dev; a.B = B; a.H = H; a.W = W; a.Cout = Cout; a.taps = folded_up ? 4 : ksize * ksize;
     a.stats = stats_dev;       // [B][cddpm_stat_records(H, W, folded_up ? 1 : 0)][Cout][2]: the output's GroupNorm statistics records, for free
@@ -1842,13 +1843,14 @@ int cddpm_op_enc_avgpool(cddpm_handle h, const float* x_dev, float* g_dev, int B
     OP_EPILOGUE()
 }
 
-int cddpm_op_gn_silu_backward(cddpm_handle h, const float* x_dev, const float* da_dev, const float* gamma_host,
-                              const float* beta_host, const float* film_dev, int silu, float* dx_dev, float* dgamma_dev,
+int cddpm_op_gn_silu_backward(cddpm_handle h, const float* x_dev, const float* x1_dev, int C1, const float* da_dev, const float* gamma_host,
+                              const float* beta_host, const float* film_dev, int silu, float* dx_dev, float* dx1_dev, float* dgamma_dev,
                               float* dbeta_dev, float* dfilm_dev, const float* rec_dev, int nrec, const float* add_dev, int B, int HW, int C,
                               void* stream) {
     if (!h) return -1;
-    if (C % 32 || C <= 0 || C > 1024 || B < 1 || HW < 1 || (rec_dev && nrec < 1))
-        return fail(h, "cddpm_op_gn_silu_backward: unsupported shape (C %d)", C);
+    if (C % 32 || C <= 0 || C > 1024 || B < 1 || HW < 1 || (rec_dev && nrec < 1) || C1 < 0 || C1 % 4 || C1 >= C ||
+        (C1 > 0 && (!x1_dev || !dx1_dev || !rec_dev)))
+        return fail(h, "cddpm_op_gn_silu_backward: unsupported shape (C %d, C1 %d; a two-source input needs its statistics records)", C, C1);
     if (!x_dev || !da_dev || !gamma_host || !beta_host || !dx_dev || !dgamma_dev || !dbeta_dev || (film_dev && !dfilm_dev))
         return fail(h, "cddpm_op_gn_silu_backward: NULL argument");
     hipStream_t s = (hipStream_t)stream;
@@ -1864,8 +1866,8 @@ int cddpm_op_gn_silu_backward(cddpm_handle h, const float* x_dev, const float* d
     SCRATCH_CHECK(sc)
     if (!rec_dev) launch_gn_partial(x_dev, C, B, HW, ns, rec, s);      // statistics records of x: given (kept from the forward pass) or swept here
     launch_gn_bwd_planes(rec_dev ? rec_dev : rec, rec_dev ? nrec : ns, g, bt, film_dev, B, C, HW, planes, s);
-    launch_gn_silu_backward(x_dev, da_dev, planes, g, bt, film_dev, silu, B, C, HW, ns, part, out_bc, dx_dev, dgamma_dev, dbeta_dev,
-                            dfilm_dev, add_dev, s);
+    launch_gn_silu_backward(x_dev, C1 ? x1_dev : nullptr, C - C1, C1 ? dx1_dev : nullptr, da_dev, planes, g, bt, film_dev, silu, B, C, HW, ns, part,
+                            out_bc, dx_dev, dgamma_dev, dbeta_dev, dfilm_dev, add_dev, s);
     HIPCHECK(h, hipGetLastError());
     return 0;
 }

@@ -184,7 +184,8 @@ void launch_loss(const float* out, const float* target, const float* w_b, int l2
                  hipStream_t stream);
 void launch_adam(float* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2, float eps, int step, float grad_unscale,
                  hipStream_t stream);
-void launch_gn_silu_backward(const float* x, const float* da, const float* planes, const float* gamma, const float* beta,
+void launch_gn_silu_backward(const float* x, const float* x1 /* second source of a concatenated input or nullptr */, int C0, float* dx1,
+                             const float* da, const float* planes, const float* gamma, const float* beta,
                              const float* film, int silu, int B, int C, int HW, int nsplit, double* part, float* out_bc, float* dx,
                              float* dgamma, float* dbeta, float* dfilm, const float* add /* dx += add, or nullptr */, hipStream_t stream);
 

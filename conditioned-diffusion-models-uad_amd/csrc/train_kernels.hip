@@ -36,7 +36,9 @@ __device__ __forceinline__ float dact(float u, float da, int silu) {
 }
 
 // planes: [4][B][C] = mean_g, rstd_g, g', b' per (sample, channel)
-__global__ __launch_bounds__(256) void gn_bwd_partial_kernel(const float* __restrict__ x, const float* __restrict__ da,
+// x: the GroupNorm input, possibly the channel concatenation of two tensors (x [.., C0] | x1 [.., C - C0]; C0 = C when there is one)
+__global__ __launch_bounds__(256) void gn_bwd_partial_kernel(const float* __restrict__ x, const float* __restrict__ x1, int C0,
+                                                             const float* __restrict__ da,
                                                              const float* __restrict__ planes, int B, int C, int HW, int nsplit,
                                                              int silu, double* __restrict__ part /*[B][nsplit][C][2]*/) {
     __shared__ double red[256][9];
@@ -52,9 +54,12 @@ __global__ __launch_bounds__(256) void gn_bwd_partial_kernel(const float* __rest
         const float4 gp = *reinterpret_cast<const float4*>(planes + 2 * pc + bc), bp = *reinterpret_cast<const float4*>(planes + 3 * pc + bc);
         const float m[4] = {mu.x, mu.y, mu.z, mu.w}, r[4] = {rs.x, rs.y, rs.z, rs.w};
         const float g[4] = {gp.x, gp.y, gp.z, gp.w}, bt[4] = {bp.x, bp.y, bp.z, bp.w};
+        const bool first = 4 * cq < C0;
+        const float* xsrc = first ? x + 4 * cq : x1 + (4 * cq - C0);
+        const int Cs = first ? C0 : C - C0;
         for (int p = p0 + pl; p < p1; p += npl) {
             const size_t off = ((size_t)b * HW + p) * C + 4 * cq;
-            const float4 xv = *reinterpret_cast<const float4*>(x + off), dv = *reinterpret_cast<const float4*>(da + off);
+            const float4 xv = *reinterpret_cast<const float4*>(xsrc + ((size_t)b * HW + p) * Cs), dv = *reinterpret_cast<const float4*>(da + off);
             const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, ds[4] = {dv.x, dv.y, dv.z, dv.w};
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -139,7 +144,8 @@ __global__ void gn_bwd_param_kernel(const float* __restrict__ out_bc, const floa
     dbeta[c] = (float)bt;
 }
 
-__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ da,
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ x1, int C0,
+                                                           float* __restrict__ dx1, const float* __restrict__ da,
                                                            const float* __restrict__ planes, const float* __restrict__ out_bc,
                                                            int B, int C, int HW, int silu, const float* __restrict__ add,
                                                            float* __restrict__ dx) {
@@ -153,7 +159,10 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
     const float4 mu = *reinterpret_cast<const float4*>(planes + bc), rs = *reinterpret_cast<const float4*>(planes + pc + bc);
     const float4 gp = *reinterpret_cast<const float4*>(planes + 2 * pc + bc), bt = *reinterpret_cast<const float4*>(planes + 3 * pc + bc);
     const float4 m1 = *reinterpret_cast<const float4*>(out_bc + 2 * pc + bc), m2 = *reinterpret_cast<const float4*>(out_bc + 3 * pc + bc);
-    const float4 xv = *reinterpret_cast<const float4*>(x + off), dv = *reinterpret_cast<const float4*>(da + off);
+    const bool first = 4 * cq < C0;
+    const int Cs = first ? C0 : C - C0;
+    const size_t soff = (size_t)bp * Cs + (first ? 4 * cq : 4 * cq - C0);      // offset inside the source (and destination) tensor
+    const float4 xv = *reinterpret_cast<const float4*>((first ? x : x1) + soff), dv = *reinterpret_cast<const float4*>(da + off);
     float4 o;
 #define CDDPM_GNB(f) { const float xh = (xv.f - mu.f) * rs.f; const float du = dact(xh * gp.f + bt.f, dv.f, silu); \
                        o.f = rs.f * (du * gp.f - m1.f - xh * m2.f); }
@@ -163,7 +172,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
         const float4 av = *reinterpret_cast<const float4*>(add + off);
         o.x += av.x; o.y += av.y; o.z += av.z; o.w += av.w;
     }
-    *reinterpret_cast<float4*>(dx + off) = o;
+    *reinterpret_cast<float4*>((first ? dx : dx1) + soff) = o;
 }
 
 // forward statistics for the standalone op: planes[0] = mean_g, [1] = rstd_g, [2] = g', [3] = b' from fp32 (sum, sum of squares) records.
@@ -217,14 +226,14 @@ void launch_gn_bwd_planes(const float* rec, int nrec, const float* gamma, const 
     hipLaunchKernelGGL(gn_bwd_planes_kernel, dim3(B, 4), dim3(256), 0, stream, rec, nrec, gamma, beta, film, B, C, HW, planes);
 }
 
-void launch_gn_silu_backward(const float* x, const float* da, const float* planes, const float* gamma, const float* beta,
+void launch_gn_silu_backward(const float* x, const float* x1, int C0, float* dx1, const float* da, const float* planes, const float* gamma, const float* beta,
                              const float* film, int silu, int B, int C, int HW, int nsplit, double* part, float* out_bc, float* dx,
                              float* dgamma, float* dbeta, float* dfilm, const float* add, hipStream_t stream) {
-    hipLaunchKernelGGL(gn_bwd_partial_kernel, dim3(nsplit, B), dim3(256), 0, stream, x, da, planes, B, C, HW, nsplit, silu, part);
+    hipLaunchKernelGGL(gn_bwd_partial_kernel, dim3(nsplit, B), dim3(256), 0, stream, x, x1, C0, da, planes, B, C, HW, nsplit, silu, part);
     hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(B), dim3(256), 0, stream, part, planes, gamma, beta, B, C, HW, nsplit, out_bc, dfilm);
     hipLaunchKernelGGL(gn_bwd_param_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, out_bc, film, B, C, dgamma, dbeta);
     const long long total = (long long)B * HW * (C / 4);
-    hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, x, da, planes, out_bc, B, C, HW,
+    hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, x, x1, C0, dx1, da, planes, out_bc, B, C, HW,
                        silu, add, dx);
 }
 

@@ -433,8 +433,8 @@ class CddpmEngine:
         dg = torch.empty((C,), dtype=torch.float32, device=self.device)
         db = torch.empty((C,), dtype=torch.float32, device=self.device)
         dfilm = torch.empty((B, 2 * C), dtype=torch.float32, device=self.device) if film is not None else None
-        self._ck(self.lib.cddpm_op_gn_silu_backward(self._h, x.data_ptr(), da.data_ptr(), g.ctypes.data, b.ctypes.data,
-                                                    film.data_ptr() if film is not None else None, int(bool(silu)), dx.data_ptr(),
+        self._ck(self.lib.cddpm_op_gn_silu_backward(self._h, x.data_ptr(), None, 0, da.data_ptr(), g.ctypes.data, b.ctypes.data,
+                                                    film.data_ptr() if film is not None else None, int(bool(silu)), dx.data_ptr(), None,
                                                     dg.data_ptr(), db.data_ptr(), dfilm.data_ptr() if dfilm is not None else None, None, 0, None,
                                                     B, H * W, C, _stream_ptr(self.device)), "cddpm_op_gn_silu_backward")
         return dx, dg, db, dfilm

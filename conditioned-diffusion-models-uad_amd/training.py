@@ -239,17 +239,26 @@ class UNetTrainer:
                                                _p(coef), B, HW, self._s()), "op_gn_coef")
         return coef
 
-    def gn_bwd(self, x, da, name, film=None, silu=True, rec=None, add=None):
-        """backward of act(GroupNorm32(x) (1 + scale) + shift): dgamma / dbeta go to the gradient buffer; -> (dx, dfilm or None).
-        rec: x's statistics records kept from the forward pass (else they are swept again); add: a tensor added to dx (skip-path gradient)"""
-        B, H, W, Cc = x.shape
+    def gn_bwd(self, x, da, name, film=None, silu=True, rec=None, add=None, x1=None):
+        """backward of act(GroupNorm32(cat[x, x1]) (1 + scale) + shift): dgamma / dbeta go to the gradient buffer; -> (dx, dfilm or None),
+        dx = (dx, dx1) when x1 is given (the input gradient split like the input). rec: the input's statistics records kept from the
+        forward pass (else they are swept again); add: a tensor over all channels added to dx (skip-path gradient)"""
+        B, H, W, c0 = x.shape
+        two = x1 is not None
+        if two and rec is None:                   # no records for the pair: one concatenated tensor, swept
+            x, x1 = torch.cat([x, x1], dim=-1), None
+        C1 = x1.shape[-1] if x1 is not None else 0
+        Cc = x.shape[-1] + C1
         dx = torch.empty_like(x)
+        dx1 = torch.empty_like(x1) if x1 is not None else None
         dfilm = self._new(B, 2 * Cc) if film is not None else None
-        self._ck(self.lib.cddpm_op_gn_silu_backward(self.h, _p(x), _p(da), _p(self.p[name + ".weight"]), _p(self.p[name + ".bias"]), _p(film),
-                                                    int(bool(silu)), _p(dx), _p(self.g[name + ".weight"]), _p(self.g[name + ".bias"]), _p(dfilm),
-                                                    _p(rec), rec.shape[1] if rec is not None else 0, _p(add), B, H * W, Cc, self._s()),
+        self._ck(self.lib.cddpm_op_gn_silu_backward(self.h, _p(x), _p(x1), C1, _p(da), _p(self.p[name + ".weight"]), _p(self.p[name + ".bias"]), _p(film),
+                                                    int(bool(silu)), _p(dx), _p(dx1), _p(self.g[name + ".weight"]), _p(self.g[name + ".bias"]),
+                                                    _p(dfilm), _p(rec), rec.shape[1] if rec is not None else 0, _p(add), B, H * W, Cc, self._s()),
                  "op_gn_silu_backward")
-        return dx, dfilm
+        if two and dx1 is None:
+            dx, dx1 = dx[..., :c0].contiguous(), dx[..., c0:].contiguous()
+        return ((dx, dx1) if two else dx), dfilm
 
     def rec_of(self, x0, x1=None):
         """statistics records of cat[x0, x1] when both sources have records of the same count (record tensors concatenate along channels)"""
@@ -261,7 +270,8 @@ class UNetTrainer:
             return None
         return torch.cat([r0, r1], dim=2).contiguous()
 
-    def conv(self, name, x0, x1=None, coef=None, silu=False, res=None, res_up=False, skip=None, skip_name=None, bias=None, stats=True):
+    def conv(self, name, x0, x1=None, coef=None, silu=False, res=None, res_up=False, skip=None, skip_name=None, bias=None, stats=True,
+             skip1=None):
         """fused forward convolution `name` on its packed image: conv_k(act(cat[x0, x1])) [+ conv1x1(skip)] + bias [+ res]"""
         co, ci, ks, folded, _g = self._convs[name]
         B, h_, w_, C0 = x0.shape
@@ -272,6 +282,7 @@ class UNetTrainer:
         self._ck(self.lib.cddpm_op_conv_packed(
             self.h, _p(x0), C0, _p(x1), x1.shape[-1] if x1 is not None else 0, _p(coef), int(bool(silu)), int(folded), _p(self.pk[name]), self.wexp[name],
             _p(b), co, ks, _p(res), int(bool(res_up)), _p(skip), skip.shape[-1] if skip is not None else 0,
+            _p(skip1), skip1.shape[-1] if skip1 is not None else 0,
             _p(self.pk[skip_name]) if skip_name else None, _p(out), _p(rec), B, H, W, self._s()), "op_conv_packed")
         if rec is not None:
             self.rec[out.data_ptr()] = rec          # GroupNorm statistics of the output, written by the convolution's epilogue
@@ -283,7 +294,7 @@ class UNetTrainer:
         B, H, W, _c = dy.shape
         dx = self._new(B, H, W, ci)
         self._ck(self.lib.cddpm_op_conv_packed(self.h, _p(dy), co, None, 0, None, 0, 0, _p(self.pkT[name]), self.wexp[name], None, ci, ks, None, 0,
-                                               None, 0, None, _p(dx), None, B, H, W, self._s()), "op_conv_packed (input gradient)")
+                                               None, 0, None, 0, None, _p(dx), None, B, H, W, self._s()), "op_conv_packed (input gradient)")
         return dx
 
     def wgrad(self, name, x0, x1, coef, silu, dy, upsample=False, bias=True):
@@ -371,10 +382,8 @@ class UNetTrainer:
                     resid, res_up = cur, False
                 coef2 = self.gn_coef(h1, None, name + ".out_layers.0", film)
                 r.update(h1=h1, coef2=coef2, rec_h1=self.rec_of(h1))
-                if a["cin"] != a["cout"]:
-                    xin = cur if x1 is None else torch.cat([cur, x1], dim=-1)
-                    r["xin"] = xin
-                    out = self.conv(c2, h1, None, coef2, True, skip=xin, skip_name=name + ".skip_connection",
+                if a["cin"] != a["cout"]:        # the 1x1 skip_connection reads cat[cur, x1] as two tensors: nothing is concatenated in memory
+                    out = self.conv(c2, h1, None, coef2, True, skip=cur, skip1=x1, skip_name=name + ".skip_connection",
                                     bias=p[c2 + ".bias"] + p[name + ".skip_connection.bias"])
                 else:
                     out = self.conv(c2, h1, None, coef2, True, res=resid, res_up=res_up)
@@ -465,12 +474,11 @@ class UNetTrainer:
                 else:
                     da1 = self.dgrad(c1, dh1)
                     self.wgrad(c1, x0, x1, r["coef1"], True, dh1)
-                    dx, _ = self.gn_bwd(r["xin"] if x1 is not None else x0, da1, name + ".in_layers.0", rec=r["rec_in"],
+                    dx, _ = self.gn_bwd(x0, da1, name + ".in_layers.0", rec=r["rec_in"], x1=x1,
                                         add=dxs if dxs is not None else d)        # + the 1x1 skip_connection's gradient, or the identity skip's
-                if x1 is not None:       # split the gradient of the concatenation: [h | popped skip tensor]
-                    c0 = x0.shape[-1]
-                    skip_grads.append(dx[..., c0:].contiguous())
-                    d = dx[..., :c0].contiguous()
+                if x1 is not None:       # the gradient of the concatenation arrives split: [h | popped skip tensor]
+                    d, dskip = dx
+                    skip_grads.append(dskip)
                 else:
                     d = dx
             else:   # input conv

@@ -325,8 +325,9 @@ int cddpm_op_pack_conv(cddpm_handle h, const float* w_dev, int Cout, int Cin, in
                        void* stream);
 int cddpm_op_conv_packed(cddpm_handle h, const float* src0_dev, int C0, const float* src1_dev, int C1, const float* coef_dev, int silu,
                          int folded_up, const void* packed_dev, int scale_exp, const float* bias_dev, int Cout, int ksize,
-                         const float* res_dev, int res_upsample, const float* skip_dev, int S0, const void* skip_packed_dev,
-                         float* out_dev, float* stats_dev, int B, int H, int W, void* stream);
+                         const float* res_dev, int res_upsample, const float* skip_dev, int S0, const float* skip1_dev, int S1,
+                         const void* skip_packed_dev, float* out_dev, float* stats_dev, int B, int H, int W, void* stream);
+/* skip1_dev / S1 (0: none): the 1x1 skip segment's input as the concatenation of two tensors (its image covers S0 + S1 channels). */
 /* stats_dev (or NULL): the output's GroupNorm statistics records [B][cddpm_stat_records(H, W, folded_up ? 1 : 0)][Cout][2], written by the
  * convolution's epilogue; cddpm_op_gn_coef_rec is cddpm_op_gn_coef on such records (no sweep over the tensors), and
  * cddpm_op_gn_silu_backward takes them through rec_dev / nrec. */
@@ -366,10 +367,12 @@ int cddpm_op_enc_maxpool(cddpm_handle h, const float* x_dev, float* y_dev, int B
 int cddpm_op_enc_avgpool(cddpm_handle h, const float* x_dev, float* g_dev, int B, int HW, int C, int backward, void* stream);
 
 /* backward of a = act(GroupNorm32(x) * (1 + scale) + shift), act = SiLU (silu != 0) or identity (OpenAI_Unet.py:284-338, :325-330):
- * given da_dev [B,HW,C] writes dx_dev [B,HW,C], dgamma_dev / dbeta_dev [C] and, when film_dev ([B][2C] scale | shift) is given,
+ * given da_dev [B,HW,C] writes dx_dev [B,HW,C] (with x1_dev: x = cat[x_dev [.., C - C1], x1_dev [.., C1]], the input gradient split the same
+ * way into dx_dev / dx1_dev; needs rec_dev), dgamma_dev / dbeta_dev [C] and, when film_dev ([B][2C] scale | shift) is given,
  * dfilm_dev [B][2C]. The forward statistics are recomputed from x_dev. Everything NHWC fp32. */
-int cddpm_op_gn_silu_backward(cddpm_handle h, const float* x_dev, const float* da_dev, const float* gamma_host,
-                              const float* beta_host, const float* film_dev, int silu, float* dx_dev, float* dgamma_dev,
+int cddpm_op_gn_silu_backward(cddpm_handle h, const float* x_dev, const float* x1_dev /* second tensor of a concatenated input, or NULL */, int C1,
+                              const float* da_dev, const float* gamma_host,
+                              const float* beta_host, const float* film_dev, int silu, float* dx_dev, float* dx1_dev /* [B,HW,C1] */, float* dgamma_dev,
                               float* dbeta_dev, float* dfilm_dev, const float* rec_dev /* x's statistics records or NULL */, int nrec,
                               const float* add_dev /* [B,HW,C] added to dx (the gradient of a parallel skip path), or NULL */, int B, int HW, int C,
                               void* stream);
