@@ -25,7 +25,8 @@ def _loss_of(out, target, p2w, loss_type):
     return per.mean()
 
 
-@pytest.mark.parametrize("B,H,W,objective,loss_type", [(2, 32, 32, "pred_x0", "l1"), (2, 16, 48, "pred_noise", "l2")])
+@pytest.mark.parametrize("B,H,W,objective,loss_type", [(2, 32, 32, "pred_x0", "l1"), (2, 16, 48, "pred_noise", "l2"),
+                                                        (1, 96, 96, "pred_x0", "l1")])       # 96 x 96: the experiment's own slice size (24 x 24 = 576 tokens)
 def test_loss_and_all_gradients_vs_autograd(oracle, synth, sd_np, B, H, W, objective, loss_type):
     """Yardstick: float64 autograd through the oracle's UNet. The L1 loss's derivative sign(out - target) is discontinuous, so the chain
     is checked in two links that share no ambiguity: (1) loss and dL/d(out) from the HIP loss kernel against autograd of the loss formula
