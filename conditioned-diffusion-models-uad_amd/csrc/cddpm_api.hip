@@ -1324,7 +1324,6 @@ int cddpm_op_conv_packed(cddpm_handle h, const float* src0, int C0, const float*
                          int res_upsample, const float* skip_dev, int S0, const float* skip1_dev, int S1, const void* skip_packed_dev,
                          float* out_dev, float* stats_dev, int B, int H, int W, void* stream) {
     if (!h) return -1;
-    const int Cin = C0 + C1;
     if (conv_mode() != 2) return fail(h, "cddpm_op_conv_packed: default convolution family (CDDPM_CONV=h3) only");
     if ((ksize != 1 && ksize != 3) || C0 <= 0 || C0 % 32 || C1 < 0 || C1 % 32 || Cout <= 0 || Cout % 128 || Cout > 4096 || B < 1 || H < 1 || W < 1 ||
         (folded_up && (ksize != 3 || C1 || H % 2 || W % 2)) || (skip_dev && (S0 <= 0 || S0 % 32 || !skip_packed_dev || ksize != 3 || S1 < 0 || S1 % 32 || (S1 > 0 && !skip1_dev))) ||
