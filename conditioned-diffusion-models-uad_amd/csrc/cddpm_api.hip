@@ -1342,6 +1342,9 @@ int cddpm_op_conv_packed(cddpm_handle h, const float* src0, int C0, const float*
     a.wscale_inv = ldexpf(1.0f, -scale_exp);
     a.out = out_dev; a.B = B; a.H = H; a.W = W; a.Cout = Cout; a.taps = folded_up ? 4 : ksize * ksize;
     a.stats = stats_dev;       // [B][cddpm_stat_records(H, W, folded_up ? 1 : 0)][Cout][2]: the output's GroupNorm statistics records, for free
+    // CDDPM_TRAIN_PRECISION=16: the training operators multiply plain fp16 operands (hi terms only), as the reference trainer's precision 16 does
+    static const int train16 = [] { const char* e = getenv("CDDPM_TRAIN_PRECISION"); return (e && !strcmp(e, "16")) ? 1 : 0; }();
+    a.hi_only = train16;
     launch_conv(a, (hipStream_t)stream);
     HIPCHECK(h, hipGetLastError());
     return 0;

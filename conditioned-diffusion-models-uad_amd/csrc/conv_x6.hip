@@ -69,7 +69,9 @@ namespace cddpm {
 // M16X: the fp16 form on v_mfma_f32_16x16x32_f16 (one MFMA spans a tap's whole 32-channel chunk; 16 tiles of 16 x 16 per
 // wave) instead of 32x32x16: the same cycle count, but the chip holds a higher clock on this shape -- the default of the
 // fp16 form (the 32x32x16 instances stay for CDDPM_M16=0); half as many accumulate roundings per product.
-template <int TAPS, int ROWS, int NS, bool M16X = false>
+// HI1: multiply the hi terms only (plain fp16 operands, fp32 accumulation: the training operators under CDDPM_TRAIN_PRECISION=16); its own
+// instantiation, so that the reconstruction path's kernel is unchanged by it
+template <int TAPS, int ROWS, int NS, bool M16X = false, bool HI1 = false>
 __global__ __launch_bounds__(64 * ROWS) void conv_split_kernel(const ConvArgs a) {
     typedef typename SplitT<NS>::v8 frag;
     constexpr int SP = 4 * NS;                          // 16-B slots per pixel / per cout row
@@ -375,7 +377,8 @@ __global__ __launch_bounds__(64 * ROWS) void conv_split_kernel(const ConvArgs a)
 #pragma unroll
                 for (int p = 0; p < 3; ++p) {       // mid*hi, hi*mid, hi*hi
                     const int sa = (p == 0) ? 1 : 0, sb = (p == 1) ? 1 : 0;
-                    if (p == 0 && first) {
+                    if constexpr (HI1) { if (p < 2) continue; }         // plain fp16 operands: the hi x hi product only
+                    if ((HI1 ? p == 2 : p == 0) && first) {
 #pragma unroll
                         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -828,17 +831,25 @@ static void launch_split(const ConvArgs& a, hipStream_t stream) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_split_kernel<1, ROWS, NS, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_split_kernel<4, ROWS, NS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_split_kernel<4, ROWS, NS, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if constexpr (NS == 2) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_split_kernel<9, ROWS, NS, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_split_kernel<1, ROWS, NS, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_split_kernel<4, ROWS, NS, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        }
         attr = true;
     }
     const dim3 g(grid), blk(64 * ROWS);
     if (a.taps == 9) {
-        if (m16) hipLaunchKernelGGL((conv_split_kernel<9, ROWS, NS, true>), g, blk, need((ROWS + 2) * 34), stream, a);
+        if (m16 && a.hi_only) hipLaunchKernelGGL((conv_split_kernel<9, ROWS, NS, true, true>), g, blk, need((ROWS + 2) * 34), stream, a);
+        else if (m16) hipLaunchKernelGGL((conv_split_kernel<9, ROWS, NS, true>), g, blk, need((ROWS + 2) * 34), stream, a);
         else     hipLaunchKernelGGL((conv_split_kernel<9, ROWS, NS>), g, blk, need((ROWS + 2) * 34), stream, a);
     } else if (a.taps == 1) {
-        if (m16) hipLaunchKernelGGL((conv_split_kernel<1, ROWS, NS, true>), g, blk, need(ROWS * 32), stream, a);
+        if (m16 && a.hi_only) hipLaunchKernelGGL((conv_split_kernel<1, ROWS, NS, true, true>), g, blk, need(ROWS * 32), stream, a);
+        else if (m16) hipLaunchKernelGGL((conv_split_kernel<1, ROWS, NS, true>), g, blk, need(ROWS * 32), stream, a);
         else     hipLaunchKernelGGL((conv_split_kernel<1, ROWS, NS>), g, blk, need(ROWS * 32), stream, a);
     } else {
-        if (m16) hipLaunchKernelGGL((conv_split_kernel<4, ROWS, NS, true>), g, blk, need((ROWS + 1) * 33), stream, a);
+        if (m16 && a.hi_only) hipLaunchKernelGGL((conv_split_kernel<4, ROWS, NS, true, true>), g, blk, need((ROWS + 1) * 33), stream, a);
+        else if (m16) hipLaunchKernelGGL((conv_split_kernel<4, ROWS, NS, true>), g, blk, need((ROWS + 1) * 33), stream, a);
         else     hipLaunchKernelGGL((conv_split_kernel<4, ROWS, NS>), g, blk, need((ROWS + 1) * 33), stream, a);
     }
 }

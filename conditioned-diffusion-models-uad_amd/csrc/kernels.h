@@ -41,6 +41,10 @@ struct ConvArgs {
     // of `out` ([ksplit][B][H][W][Cout]; the caller passes no bias / residual / stats) and launch_conv_reduce combines the planes.
     int ksplit;
     short kbound[CDDPM_MAX_KSPLIT + 1];
+    // fp16-split family, 16 x 16 form only: 1 = multiply the hi terms only (plain fp16 operands, fp32 accumulation -- the arithmetic of the
+    // reference trainer's `precision: 16`; a third of the MFMAs). Set by the training operators under CDDPM_TRAIN_PRECISION=16, never by
+    // the reconstruction path.
+    int hi_only;
 };
 // out[b][p][c] = ((plane 0 + plane 1) + ...) + bias[c] + residual, in this fixed order; optional GroupNorm statistics records of
 // `out`: one record per 64 consecutive pixels, [B][ceil(HW / 64)][Cout][2]

@@ -743,6 +743,8 @@ int wgrad_mode() {
     static int mode = -1;
     if (mode < 0) {
         const char* e = getenv("CDDPM_WGRAD");
+        const char* tp = getenv("CDDPM_TRAIN_PRECISION");      // "16": plain fp16 operands everywhere in the training step (default family h1)
+        if (!e && tp && !strcmp(tp, "16")) e = "h1";
         mode = (e && !strcmp(e, "f32")) ? 0 : (e && !strcmp(e, "h1")) ? 1 : 2;
     }
     return mode;

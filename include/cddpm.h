@@ -317,6 +317,9 @@ int cddpm_op_adam(cddpm_handle h, float* p_dev, const float* g_dev, float* m_dev
  * Cout inputs; cddpm_packed_conv_bytes(Cin, Cout, k*k) bytes), 2 = the four folded classes of "nearest x2 upsample -> conv3x3"
  * (4 * cddpm_packed_conv_bytes(Cout, Cin, 4) bytes; the class sums can reach 4 max|w|). Bit-identical to the host packer for the same
  * exponent. Default convolution family only.
+ * Environment CDDPM_TRAIN_PRECISION=16 (read once per process): cddpm_op_conv_packed multiplies plain fp16 operands (the hi terms of the
+ * images only, fp32 accumulation) and cddpm_op_conv_wgrad defaults to its h1 family -- the arithmetic of the reference trainer's precision 16.
+ * The reconstruction entry points (cddpm_reverse, cddpm_unet_forward, ...) are not affected.
  * cddpm_op_conv_packed: cddpm_op_conv / cddpm_op_conv_skip on such images: out = conv_k(act(cat[src0, src1])) [+ conv1x1(skip)] + bias
  * [+ res]; bias_dev NULL = none; skip_dev NULL = no skip segment (its image shares scale_exp); folded_up: src0 is at H/2 x W/2. */
 int cddpm_op_set_scratch(cddpm_handle h, size_t bytes);
