@@ -36,6 +36,8 @@ Extra objects on the JSON line:
   config.small_batch the reference's real call shape (DDPM_2D.py:193: 4 slices per volume): B = 4, 50 reverse steps.
   config.training_step  BASELINE config 5's per-GPU share (16 x 1 x 128 x 128, noise-prediction MSE, Adam; the context encoder trained jointly,
                 as the reference does): ms per optimisation step on the HIP operators (training.py), 1 warm-up + 3 timed steps.
+  config.training_step_precision16  the same step under CDDPM_TRAIN_PRECISION=16 (plain fp16 operands, fp32 accumulation: the reference
+                trainer's `precision: 16`), in a child process.
 """
 from __future__ import annotations
 
@@ -350,6 +352,14 @@ def main():
             out["config"]["training_step"] = training_rate(torch, dev, synth)
         except Exception as e:
             out["config"]["training_step"] = {"error": repr(e)}
+        try:        # the same step with the reference trainer's precision-16 arithmetic (chosen once per process: a child)
+            r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "train_step_bench.py"), "--batch", "16",
+                                "--encoder", "--steps", "3", "--warmup", "1"], env=dict(os.environ, CDDPM_TRAIN_PRECISION="16"), capture_output=True,
+                               text=True, timeout=300)
+            t16 = json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else {"error": r.stderr[-300:]}
+            out["config"]["training_step_precision16"] = {k: t16[k] for k in ("ms_per_step", "slices_per_s", "losses", "error") if k in t16}
+        except Exception as e:
+            out["config"]["training_step_precision16"] = {"error": repr(e)}
     if rank == 0 and world == 1 and not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(synth, S)
         out["config"]["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
