@@ -265,6 +265,26 @@ class DDPM_2D(_Base):
                 pass
         return {"loss": loss.detach()}
 
+    @torch.no_grad()
+    def validation_step(self, batch, batch_idx: int):
+        """reference :137-155: the training loss on a validation batch -- context = encoder(input), `gen_noise` or Gaussian noise, a random
+        timestep per slice, `loss, reco = self.diffusion(input, cond=features, noise=noise)` -- forward only, on the HIP path"""
+        input = batch["vol"]["data"].squeeze(-1).float()
+        features = self(input)
+        noise = self._gen_noise(input.shape, input.device)
+        with torch.autocast("cuda", enabled=False):
+            loss, _reco = self.diffusion(input, cond=features, noise=noise)
+        if hasattr(self, "log") and _Base is not nn.Module:
+            try:
+                self.log(f"{self.prefix}val/Loss_comb", loss, prog_bar=False, on_step=False, on_epoch=True, batch_size=input.shape[0], sync_dist=True)
+            except Exception:
+                pass
+        return {"loss": loss}
+
+    def update_prefix(self, prefix):
+        """reference :308"""
+        self.prefix = prefix
+
     @property
     def automatic_optimization(self):        # Lightning: training_step above steps the optimizer itself
         return False

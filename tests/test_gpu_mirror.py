@@ -236,3 +236,26 @@ def test_ddpm2d_training_step_trains_the_native_encoder_jointly(sd_np, synth):
     c1 = mod(inp)
     assert torch.isfinite(c1).all() and float((c1 - c0).abs().max()) > 1e-4
     print("joint training losses", losses)
+
+
+def test_ddpm2d_validation_step(sd_np, synth):
+    """reference src/models/DDPM_2D.py:137-155: forward-only loss of a validation batch (random t per slice, Gaussian noise when cfg.noisetype
+    is unset) -- finite, in the range of the training loss, and it leaves the weights alone"""
+    M = load_pkg("DDPM_2D")
+    cfg = dict(imageDim=[64, 64, 100], rescaleFactor=2, unet_dim=128, dim_mults=[1, 2, 2], condition=True, test_timesteps=500, timesteps=1000)
+
+    class Enc(torch.nn.Module):
+        def forward(self, x):
+            return x.flatten(1)[:, :128].contiguous() * 2 - 1
+
+    mod = M.DDPM_2D(cfg, encoder=Enc())
+    mod.diffusion.model.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()})
+    mod = mod.cuda()
+    vol = torch.from_numpy(synth.synth_slices(4, 0, 3, 32, 32)).reshape(3, 1, 32, 32, 1).cuda()
+    w0 = mod.diffusion.model.state_dict()["out.2.weight"].clone()
+    torch.manual_seed(3)
+    out = mod.validation_step({"vol": {"data": vol}}, 0)
+    assert torch.isfinite(out["loss"]) and 0.05 < float(out["loss"]) < 2.0
+    assert torch.equal(mod.diffusion.model.state_dict()["out.2.weight"], w0)
+    mod.update_prefix("fold1/")
+    assert mod.prefix == "fold1/"
