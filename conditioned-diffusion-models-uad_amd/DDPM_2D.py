@@ -187,6 +187,28 @@ class DDPM_2D(_Base):
                 _test_step(self, final_volume, data_orig, data_seg, data_mask, batch_idx, batch.get("ID"), batch.get("label"))
         return out
 
+    def on_test_start(self):
+        """reference :156-170: the bookkeeping `_test_step` / `_test_end` of the reference's evaluation write into. The metric code itself
+        (src/utils/utils_eval.py: sklearn / monai / skimage) is outside the hot path and is used from the reference tree when this class
+        runs inside it; standalone, the lists are created and test_step returns its reconstruction without the metric pass."""
+        try:
+            from src.utils.utils_eval import get_eval_dictionary  # type: ignore  (reference tree on sys.path)
+            self.eval_dict = get_eval_dictionary()
+        except Exception:
+            pass
+        self.inds, self.latentSpace_slice, self.diffs_list, self.seg_list = [], [], [], []
+        self.new_size = [160, 190, 160]
+        if not hasattr(self, "threshold"):
+            self.threshold = {}
+
+    def on_test_end(self):
+        """reference :288-291: `_test_end(self)` of the reference's utils_eval when it is importable; nothing to aggregate otherwise"""
+        try:
+            from src.utils.utils_eval import _test_end  # type: ignore
+        except Exception:
+            return
+        _test_end(self)
+
     # ------------------------------------------------------------------ training (reference :114-135, :305-306)
     def hip_trainer(self, device):
         """the UNet's training state on the HIP operators (training.UNetTrainer). From here on the UNet module's parameters ARE views of
