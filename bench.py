@@ -2,6 +2,8 @@
 """bench.py -- reconstructed 128x128 slices/sec @ T=1000 of the cDDPM reverse-diffusion path on MI355X.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--size S] [--no-cpu] [--no-alt] [--no-profile]
+        (N > 1 without RANK in the environment: starts the N ranks itself -- the torchrun line below as a child process --
+         and relays rank 0's JSON line)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -178,6 +180,36 @@ def short_rate(torch, dev, B, S, n_rev, warm):
             "finite": finite}
 
 
+def launch_plan(gpus: int, argv, env, script=None):
+    """`python bench.py --gpus N` with N > 1 and no RANK in the environment is a request to run N ranks, not a rank: the
+    command line of the launcher child (one process per GPU over RCCL, rendezvous on 127.0.0.1), or None when this process
+    is itself a rank (under torchrun) or N == 1. Decided BEFORE anything touches the GPU: the launcher process never does."""
+    if gpus <= 1 or "RANK" in env:
+        return None
+    import socket
+    port = env.get("MASTER_PORT")
+    if not port:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = str(s.getsockname()[1])
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), script or os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(cmd, env):
+    """run the launcher child, relay rank 0's JSON line (the only thing the ranks write to stdout), exit with its code"""
+    env = dict(env)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL needs it on this driver
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    if lines:
+        sys.stdout.write(lines[-1] + "\n")
+        sys.stdout.flush()
+    if r.returncode != 0 or not lines:
+        raise SystemExit(r.returncode or 1)
+    raise SystemExit(0)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -190,6 +222,10 @@ def main():
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP event pass (no roofline object)")
     ap.add_argument("--alt-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+
+    plan = launch_plan(args.gpus, sys.argv[1:], os.environ)
+    if plan is not None:
+        self_launch(plan, os.environ)
 
     # stdout carries exactly ONE line (the JSON result): anything libraries print there (RCCL's version banner,
     # MIOpen/HIP notices) is sent to stderr for the duration of the run

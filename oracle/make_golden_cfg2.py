@@ -116,12 +116,18 @@ if __name__ == "__main__":
     ap.add_argument("--stage", default="all", choices=("ref", "oracle", "fp64", "all"))
     ap.add_argument("--small", action="store_true", help="32x32 instead of 128x128")
     ap.add_argument("--threads", type=int, default=0)
+    ap.add_argument("--tag", default="", help="suffix of the output name (reference stage only): a second run of the "
+                    "REFERENCE under another thread count, e.g. --threads 4 --tag threads4 -- what the reference "
+                    "differs from ITSELF by at full length")
     a = ap.parse_args()
     if a.threads:
         torch.set_num_threads(a.threads)
     B, T = 2, 1000
     H = W = 32 if a.small else 128
     name = f"loop_B2_32x32_T1000_start0" if a.small else "loop_cfg2_B2_128x128_T1000_start0"
+    if a.tag:
+        assert a.stage == "ref", "--tag is for a second reference run only"
+        name = name + "_" + a.tag
     base = dict(B=B, H=H, W=W, timesteps=T, start_t=0, captured_t=list(CAPTURE_T),
                 seeds=dict(weights=SEED_W, cond=SEED_COND, xT=SEED_XT, z=SEED_Z))
     if a.stage in ("ref", "all"):

@@ -1,5 +1,6 @@
 """Times the training step (training.py: forward + loss + backward + Adam, all on the HIP operators) on one GPU.
     python tools/train_step_bench.py [--batch 16] [--size 128] [--steps 5] [--warmup 2]
+    python tools/train_step_bench.py --gpus N            (starts the N ranks itself: the line below as a child process)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 tools/train_step_bench.py   (data-parallel, RCCL)
 BASELINE config 5 is 128x1x128x128 over 8 GPUs data-parallel = 16 slices per GPU and step (weak scaling: --batch is per rank)."""
 import argparse
@@ -8,8 +9,6 @@ import json
 import os
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -24,7 +23,13 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--encoder", action="store_true", help="train the context encoder (ResNet-50) jointly, as the reference does")
     ap.add_argument("--phases", action="store_true", help="time forward / backward / adam separately (synchronises between them)")
+    ap.add_argument("--gpus", type=int, default=1, help="N > 1 without RANK in the environment: start the N ranks (torchrun child) and relay rank 0's line")
     a = ap.parse_args()
+    from bench import launch_plan, self_launch           # decided before anything touches the GPU
+    plan = launch_plan(a.gpus, sys.argv[1:], os.environ, script=os.path.abspath(__file__))
+    if plan is not None:
+        self_launch(plan, os.environ)
+    import torch
     tr = importlib.import_module(PKG + ".training")
     synth = importlib.import_module(PKG + ".synth")
     world, rank, local = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
