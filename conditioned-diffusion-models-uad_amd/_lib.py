@@ -93,6 +93,11 @@ SYMBOLS = {
     "cddpm_op_head_dgrad": (_i, [_vp, _fp, _fp, _fp, _i, _i, _i, _i, _vp]),
     "cddpm_op_loss": (_i, [_vp, _fp, _fp, _fp, _i, _i, _i, C.c_float, _fp, _fp, _vp]),
     "cddpm_op_adam": (_i, [_vp, _fp, _fp, _fp, _fp, _i64, C.c_float, C.c_float, C.c_float, C.c_float, _i, C.c_float, _vp]),
+    "cddpm_set_train_precision": (_i, [_i]),
+    "cddpm_get_train_precision": (_i, []),
+    "cddpm_op_grad_check": (_i, [_vp, _fp, _i64, _vp, _vp]),
+    "cddpm_op_guard_commit": (_i, [_vp, _vp, C.c_float, C.c_float, _vp]),
+    "cddpm_op_adam_guarded": (_i, [_vp, _fp, _fp, _fp, _fp, _i64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _vp, _vp]),
     "cddpm_op_gn_silu_backward": (_i, [_vp, _fp, _fp, _i, _fp, _fp, _fp, _fp, _i, _fp, _fp, _fp, _fp, _fp, _fp, _i, _fp, _i, _i, _i, _vp]),
     "cddpm_op_enc_pack_w": (_i, [_vp, _fp, _i, _i, _i, _fp, _fp, _vp]),
     "cddpm_op_enc_conv": (_i, [_vp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),

@@ -49,12 +49,20 @@ def build_lib(force: bool = False, verbose: bool = False, defines=(), tag: str =
         # A/B of older conv kernels: an alternative file replaces conv_x6.hip if its name starts with conv_x6, else conv_mfma.hip
         swap = "conv_x6.hip" if os.path.basename(conv_src).startswith("conv_x6") else "conv_mfma.hip"
         path = conv_src if (conv_src and src == swap) else os.path.join(CSRC, src)
+        deps = [path, os.path.join(CSRC, "kernels.h"), os.path.join(CSRC, "conv_split.h"),
+                os.path.join(os.path.dirname(os.path.dirname(CSRC)), "include", "cddpm.h"), os.path.abspath(__file__)]
+        stamp = obj + ".flags"          # an object is reused when it is newer than its inputs and was built with the same flags
+        if (not force and os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == " ".join(flags + [path])
+                and all(os.path.getmtime(d) <= os.path.getmtime(obj) for d in deps if os.path.exists(d))):
+            return obj
         cmd = [hipcc, *flags, f"-I{CSRC}", "-c", path, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}:\n{r.stderr}")
         if verbose and r.stderr.strip():
             print(r.stderr, file=sys.stderr)
+        with open(stamp, "w") as f:
+            f.write(" ".join(flags + [path]))
         return obj
 
     with ThreadPoolExecutor(max_workers=min(7, os.cpu_count() or 1)) as ex:

@@ -1343,8 +1343,7 @@ int cddpm_op_conv_packed(cddpm_handle h, const float* src0, int C0, const float*
     a.out = out_dev; a.B = B; a.H = H; a.W = W; a.Cout = Cout; a.taps = folded_up ? 4 : ksize * ksize;
     a.stats = stats_dev;       // [B][cddpm_stat_records(H, W, folded_up ? 1 : 0)][Cout][2]: the output's GroupNorm statistics records, for free
     // CDDPM_TRAIN_PRECISION=16: the training operators multiply plain fp16 operands (hi terms only), as the reference trainer's precision 16 does
-    static const int train16 = [] { const char* e = getenv("CDDPM_TRAIN_PRECISION"); return (e && !strcmp(e, "16")) ? 1 : 0; }();
-    a.hi_only = train16;
+    a.hi_only = train_precision() == 16 ? 1 : 0;
     launch_conv(a, (hipStream_t)stream);
     HIPCHECK(h, hipGetLastError());
     return 0;
@@ -1755,6 +1754,27 @@ int cddpm_op_adam(cddpm_handle h, float* p_dev, const float* g_dev, float* m_dev
                   float eps, int step, float grad_unscale, void* stream) {
     OP_PROLOGUE(p_dev && g_dev && m_dev && v_dev && n > 0 && step >= 1, "cddpm_op_adam: bad arguments")
     launch_adam(p_dev, g_dev, m_dev, v_dev, n, lr, beta1, beta2, eps, step, grad_unscale, s);
+    OP_EPILOGUE()
+}
+int cddpm_set_train_precision(int bits) {
+    if (bits != 16 && bits != 32) return -1;
+    return set_train_precision(bits);
+}
+int cddpm_get_train_precision(void) { return train_precision(); }
+int cddpm_op_grad_check(cddpm_handle h, const float* g_dev, int64_t n, int32_t* ctrl_dev, void* stream) {
+    OP_PROLOGUE(g_dev && ctrl_dev && n > 0 && ((uintptr_t)g_dev & 15) == 0, "cddpm_op_grad_check: bad arguments (g_dev 16-byte aligned)")
+    launch_grad_check(g_dev, n, ctrl_dev, s);
+    OP_EPILOGUE()
+}
+int cddpm_op_guard_commit(cddpm_handle h, int32_t* ctrl_dev, float beta1, float beta2, void* stream) {
+    OP_PROLOGUE(ctrl_dev != nullptr, "cddpm_op_guard_commit: bad arguments")
+    launch_guard_commit(ctrl_dev, beta1, beta2, s);
+    OP_EPILOGUE()
+}
+int cddpm_op_adam_guarded(cddpm_handle h, float* p_dev, const float* g_dev, float* m_dev, float* v_dev, int64_t n, float lr, float beta1,
+                          float beta2, float eps, float grad_unscale, const int32_t* ctrl_dev, void* stream) {
+    OP_PROLOGUE(p_dev && g_dev && m_dev && v_dev && ctrl_dev && n > 0, "cddpm_op_adam_guarded: bad arguments")
+    launch_adam_guarded(p_dev, g_dev, m_dev, v_dev, n, lr, beta1, beta2, eps, grad_unscale, ctrl_dev, s);
     OP_EPILOGUE()
 }
 

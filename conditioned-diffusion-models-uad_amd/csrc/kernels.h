@@ -161,6 +161,8 @@ void launch_gn_bwd_planes(const float* rec, int nrec, const float* gamma, const 
                           float* planes, hipStream_t stream);
 // conv wgrad (3x3 pad 1, or 1x1): dw [Cout][Cin][k][k] (PyTorch layout), db [Cout] or nullptr; input = cat[x0 (C0), x1 (C1)];
 // part: scratch of conv_wgrad_parts() * Cout * Cin * taps floats. Cin multiple of 32 (3x3) / 64 (1x1), C0 of 64, Cout of 64, H of 4
+int train_precision();                 // 32 (default) or 16: see train_kernels.hip
+int set_train_precision(int bits);    // returns the previous value
 int wgrad_mode();      // CDDPM_WGRAD: 2 = h3 (default), 1 = h1, 0 = f32
 int conv_wgrad_parts(int B, int H, int W, int Cin, int Cout, int taps);
 size_t conv_wgrad_image_units(int B, int H, int W, int Cin, int Cout, int taps);   // 16-byte units of `images` (0: not used by this call)
@@ -188,6 +190,10 @@ void launch_loss(const float* out, const float* target, const float* w_b, int l2
                  hipStream_t stream);
 void launch_adam(float* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2, float eps, int step, float grad_unscale,
                  hipStream_t stream);
+void launch_grad_check(const float* g, long long n, int* ctrl, hipStream_t stream);
+void launch_guard_commit(int* ctrl, float b1, float b2, hipStream_t stream);
+void launch_adam_guarded(float* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2, float eps, float grad_unscale,
+                         const int* ctrl, hipStream_t stream);
 void launch_gn_silu_backward(const float* x, const float* x1 /* second source of a concatenated input or nullptr */, int C0, float* dx1,
                              const float* da, const float* planes, const float* gamma, const float* beta,
                              const float* film, int silu, int B, int C, int HW, int nsplit, double* part, float* out_bc, float* dx,

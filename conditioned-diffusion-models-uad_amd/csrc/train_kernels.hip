@@ -18,6 +18,7 @@
 // * conv wgrad (below): a pixel-contraction GEMM on the fp32 MFMA with the activation recomputed while staging.
 // Further down: the weight-gradient families, the batched fp32 GEMM and the linear backward, resampling backward, the one-channel
 // convolutions' gradients, the loss, Adam. (Attention backward: attention.hip; the encoder: encoder_train.hip; sequencing: training.py.)
+#include <atomic>
 #include "kernels.h"
 #include <cstdlib>
 #include <cstring>
@@ -739,15 +740,31 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_img_kernel(const WgradImgAr
 
 // convolution weight-gradient family: CDDPM_WGRAD = h3 (default: fp16 two-term split, fp32-grade), h1 (plain fp16 operands), f32 (the
 // fp32-MFMA kernel above)
-int wgrad_mode() {
-    static int mode = -1;
-    if (mode < 0) {
-        const char* e = getenv("CDDPM_WGRAD");
-        const char* tp = getenv("CDDPM_TRAIN_PRECISION");      // "16": plain fp16 operands everywhere in the training step (default family h1)
-        if (!e && tp && !strcmp(tp, "16")) e = "h1";
-        mode = (e && !strcmp(e, "f32")) ? 0 : (e && !strcmp(e, "h1")) ? 1 : 2;
+// training arithmetic of the process: 32 = fp32-grade (two-term fp16 splits), 16 = plain fp16 operands with fp32 accumulation (the reference
+// trainer's `precision: 16`). Initial value from CDDPM_TRAIN_PRECISION, changed by cddpm_set_train_precision (the DDPM_2D mirror passes the
+// Trainer's precision).
+static std::atomic<int> g_train_precision{-1};
+int train_precision() {
+    int v = g_train_precision.load(std::memory_order_relaxed);
+    if (v < 0) {
+        const char* tp = getenv("CDDPM_TRAIN_PRECISION");
+        v = (tp && !strcmp(tp, "16")) ? 16 : 32;
+        g_train_precision.store(v, std::memory_order_relaxed);
     }
-    return mode;
+    return v;
+}
+int set_train_precision(int bits) {
+    const int prev = train_precision();
+    g_train_precision.store(bits == 16 ? 16 : 32, std::memory_order_relaxed);
+    return prev;
+}
+int wgrad_mode() {
+    static const int forced = [] {
+        const char* e = getenv("CDDPM_WGRAD");
+        return !e ? -1 : !strcmp(e, "f32") ? 0 : !strcmp(e, "h1") ? 1 : 2;
+    }();
+    if (forced >= 0) return forced;
+    return train_precision() == 16 ? 1 : 2;         // precision 16: plain fp16 operands everywhere in the training step
 }
 
 // dW[co][ci][t] (PyTorch layout) = sum over the P partial tiles in the order of p
@@ -1319,6 +1336,57 @@ void launch_adam(float* p, const float* g, float* m, float* v, long long n, floa
                  float grad_unscale, hipStream_t stream) {
     const float bc1 = 1.0f - powf(b1, (float)step), bc2 = 1.0f - powf(b2, (float)step);
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, p, g, m, v, n, lr, b1, b2, eps, bc1, bc2, grad_unscale);
+}
+
+// ---- guarded update: a non-finite gradient (an fp16 operand overflow in the precision-16 arithmetic, a diverging loss) must not reach the
+// parameters or Adam's moments -- what torch's GradScaler does for the reference trainer (`precision: 16`, configs/trainer/default.yaml:7):
+// the step is skipped and the optimizer's step count does not advance. All on the device, no read-back: ctrl = int32[8] =
+// {non-finite flag, step, skip this update, updates skipped so far, bits of 1 - beta1^step, bits of 1 - beta2^step, -, -}.
+__global__ __launch_bounds__(256) void grad_check_kernel(const float* __restrict__ g, long long n, int* __restrict__ ctrl) {
+    bool bad = false;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n / 4; i += (long long)gridDim.x * 256) {
+        const float4 v = reinterpret_cast<const float4*>(g)[i];
+        // (x - x) is 0 for finite x, NaN for inf / NaN
+        bad |= !((v.x - v.x) + (v.y - v.y) + (v.z - v.z) + (v.w - v.w) == 0.0f);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) { const float x = g[(n & ~3LL) + threadIdx.x]; bad |= !(x - x == 0.0f); }
+    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(ctrl, 1);
+}
+__global__ void guard_commit_kernel(int* __restrict__ ctrl, float b1, float b2) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (ctrl[0]) { ctrl[2] = 1; ctrl[3] += 1; }
+    else {
+        ctrl[2] = 0;
+        const int step = ++ctrl[1];
+        reinterpret_cast<float*>(ctrl)[4] = 1.0f - powf(b1, (float)step);
+        reinterpret_cast<float*>(ctrl)[5] = 1.0f - powf(b2, (float)step);
+    }
+    ctrl[0] = 0;
+}
+__global__ __launch_bounds__(256) void adam_guarded_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                           float* __restrict__ v, long long n, float lr, float b1, float b2, float eps,
+                                                           float unscale, const int* __restrict__ ctrl) {
+    if (ctrl[2]) return;                                   // uniform over the grid
+    const float bc1 = reinterpret_cast<const float*>(ctrl)[4], bc2 = reinterpret_cast<const float*>(ctrl)[5];
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float gi = g[i] * unscale;
+    const float mi = b1 * m[i] + (1.0f - b1) * gi;
+    const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    const float denom = sqrtf(vi) / sqrtf(bc2) + eps;
+    p[i] -= (lr / bc1) * (mi / denom);
+}
+void launch_grad_check(const float* g, long long n, int* ctrl, hipStream_t stream) {
+    const unsigned blocks = (unsigned)((n / 4 + 255) / 256 < 2048 ? ((n / 4 + 255) / 256 > 0 ? (n / 4 + 255) / 256 : 1) : 2048);
+    hipLaunchKernelGGL(grad_check_kernel, dim3(blocks), dim3(256), 0, stream, g, n, ctrl);
+}
+void launch_guard_commit(int* ctrl, float b1, float b2, hipStream_t stream) {
+    hipLaunchKernelGGL(guard_commit_kernel, dim3(1), dim3(64), 0, stream, ctrl, b1, b2);
+}
+void launch_adam_guarded(float* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2, float eps,
+                         float grad_unscale, const int* ctrl, hipStream_t stream) {
+    hipLaunchKernelGGL(adam_guarded_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, p, g, m, v, n, lr, b1, b2, eps, grad_unscale, ctrl);
 }
 
 }  // namespace cddpm

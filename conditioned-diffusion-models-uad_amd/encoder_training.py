@@ -227,12 +227,38 @@ class EncoderTrainer:
         self.saved = None
         return g
 
-    def adam_step(self, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, grad_scale=1.0):
+    def adam_step(self, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, grad_scale=1.0, guarded=False):
+        """Adam over the flat buffer under the guard of the handle's trainer (`ops`: training.UNetTrainer): the encoder and the UNet are ONE
+        optimizer in the reference (`optim.Adam(self.parameters())`, DDPM_2D.py:305-306), so the step count and the skip decision are the
+        UNet trainer's control block. guarded: `ops.guard(others=(self,))` was called for this step; else the encoder is stepped alone."""
         st = self.state
         if "m" not in st:
-            st["m"], st["v"], st["step"] = torch.zeros_like(self.flat), torch.zeros_like(self.flat), 0
-        st["step"] += 1
-        self._ck(self.lib.cddpm_op_adam(self.h, _p(self.flat), _p(self.gflat), _p(st["m"]), _p(st["v"]), self.flat.numel(), C.c_float(lr),
-                                        C.c_float(betas[0]), C.c_float(betas[1]), C.c_float(eps), st["step"], C.c_float(1.0 / grad_scale),
-                                        self._s()), "op_adam")
+            st["m"], st["v"] = torch.zeros_like(self.flat), torch.zeros_like(self.flat)
+        if not guarded:
+            if getattr(self, "ctrl", None) is None:
+                self.ctrl = torch.zeros(8, dtype=torch.int32, device=self.dev)
+            self._ck(self.lib.cddpm_op_grad_check(self.h, _p(self.gflat), self.gflat.numel(), _p(self.ctrl), self._s()), "op_grad_check")
+            self._ck(self.lib.cddpm_op_guard_commit(self.h, _p(self.ctrl), C.c_float(betas[0]), C.c_float(betas[1]), self._s()), "op_guard_commit")
+            ctrl = self.ctrl
+        else:
+            ctrl = self.ops._ctrl()
+        self._ck(self.lib.cddpm_op_adam_guarded(self.h, _p(self.flat), _p(self.gflat), _p(st["m"]), _p(st["v"]), self.flat.numel(), C.c_float(lr),
+                                                C.c_float(betas[0]), C.c_float(betas[1]), C.c_float(eps), C.c_float(1.0 / grad_scale), _p(ctrl),
+                                                self._s()), "op_adam_guarded")
+        self.repack()
+
+    def optimizer_state(self) -> Dict[str, torch.Tensor]:
+        st = self.state
+        if "m" not in st:
+            st["m"], st["v"] = torch.zeros_like(self.flat), torch.zeros_like(self.flat)
+        return {"m": st["m"].detach().clone(), "v": st["v"].detach().clone(), "layout": [(k, int(v.numel())) for k, v in self.p.items()]}
+
+    def load_optimizer_state(self, state) -> None:
+        if [tuple(x) for x in state["layout"]] != [(k, int(v.numel())) for k, v in self.p.items()]:
+            raise ValueError("encoder optimizer state was saved for another parameter layout")
+        self.state["m"] = state["m"].to(self.dev, torch.float32).clone()
+        self.state["v"] = state["v"].to(self.dev, torch.float32).clone()
+
+    def parameters_changed(self) -> None:
+        """parameters were written from outside (load_state_dict into the aliased module): rebuild the operators' weight images"""
         self.repack()

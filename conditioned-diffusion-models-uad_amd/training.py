@@ -10,8 +10,10 @@ and of the backward runs in csrc/*.hip; torch is used for device memory, views, 
 State: device-resident (flat parameter / gradient / Adam buffers, weight images re-packed on the device after every update, operator
 temporaries from one scratch arena, no synchronisation inside a step); loss and all gradients checked against float64 autograd through the
 oracle, three complete steps against float64 autograd + torch Adam (tests/test_gpu_training.py); the context encoder is trained jointly by
-encoder_training.EncoderTrainer. Convolutions keep the inference path's fp32-grade arithmetic (fp16 two-term splits); a plain-fp16
-("precision 16") forward is not offered. Measured: DESIGN.md section 4b.
+encoder_training.EncoderTrainer. Convolutions keep the inference path's fp32-grade arithmetic (fp16 two-term splits) by default; the
+reference trainer's `precision: 16` arithmetic (plain fp16 operands, fp32 accumulation) is selected per process (CDDPM_TRAIN_PRECISION=16,
+set from the Trainer's precision by the DDPM_2D mirror). A step whose gradients hold inf / NaN is skipped on the device (`guard`), as
+torch's GradScaler does for the reference. Measured: DESIGN.md section 4b.
 """
 from __future__ import annotations
 
@@ -338,10 +340,16 @@ class UNetTrainer:
         temb = torch.cat([torch.cos(args), torch.sin(args)], dim=-1).contiguous()
         y1 = self.linear(temb, "time_embed.0")
         et = self.linear(y1, "time_embed.2", silu_in=True)
-        cond = cond.float().contiguous()
-        l1 = self.linear(cond, "label_emb.0")
-        ec = self.linear(l1, "label_emb.2", silu_in=True)
-        emb = torch.cat([et, ec], dim=1).contiguous()
+        if "label_emb.0.weight" in p:
+            if cond is None:
+                raise ValueError("this UNet is conditioned (label_emb present): training needs the context vector")
+            cond = cond.float().contiguous()
+            l1 = self.linear(cond, "label_emb.0")
+            ec = self.linear(l1, "label_emb.2", silu_in=True)
+            emb = torch.cat([et, ec], dim=1).contiguous()
+        else:                       # cfg.condition False (num_classes None, OpenAI_Unet.py:583-590, :849-852): emb = time_embed(t) alone
+            cond = l1 = None
+            emb = et
         sv.update(temb=temb, y1=y1, l1=l1, cond=cond, emb=emb, x=x)
         film_all = None
         if self.emb_rows:           # FiLM (scale | shift) of all ResBlocks: one [B, E] x [E, 11776] product
@@ -492,12 +500,15 @@ class UNetTrainer:
             self._ck(self.lib.cddpm_op_linear_backward(self.h, _p(emb), _p(self.emb_w), _p(dfilm_all), B, self.emb_rows, emb.shape[1], 1,
                                                        _p(self.emb_gw), _p(self.emb_gb), _p(demb), self._s()), "op_linear_backward")
         # embedding MLPs (OpenAI_Unet.py:598-602, :583-590)
-        hw = sv["emb"].shape[1] // 2
-        det, dec = demb[:, :hw].contiguous(), demb[:, hw:].contiguous()
+        if sv["cond"] is not None:
+            hw = sv["emb"].shape[1] // 2
+            det, dec = demb[:, :hw].contiguous(), demb[:, hw:].contiguous()
+            dl1 = self.linear_bwd(sv["l1"], "label_emb.2", dec, True)
+            self.dcond = self.linear_bwd(sv["cond"], "label_emb.0", dl1, False)  # gradient w.r.t. the context vector (the encoder's input gradient)
+        else:
+            det, self.dcond = demb, None
         dy1 = self.linear_bwd(sv["y1"], "time_embed.2", det, True)
         self.linear_bwd(sv["temb"], "time_embed.0", dy1, False)
-        dl1 = self.linear_bwd(sv["l1"], "label_emb.2", dec, True)
-        self.dcond = self.linear_bwd(sv["cond"], "label_emb.0", dl1, False)      # gradient w.r.t. the context vector (the encoder's input gradient)
         self.saved = None
         return g
 
@@ -512,20 +523,99 @@ class UNetTrainer:
                                         C.c_float(self.grad_scale), _p(dout), _p(loss_b), self._s()), "op_loss")
         return loss_b.mean(), dout
 
-    def adam_step(self, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, grad_scale=None):
+    # ------------------------------------------------------------------ the guarded update (GradScaler's skip of a non-finite step)
+    def _ctrl(self):
+        """int32[8] on the device: {non-finite flag, optimizer step, skip, skipped so far, bias corrections} (include/cddpm.h,
+        cddpm_op_guard_commit); shared with an EncoderTrainer running on this handle: one optimizer, one decision"""
+        if getattr(self, "ctrl", None) is None:
+            self.ctrl = torch.zeros(8, dtype=torch.int32, device=self.dev)
+        return self.ctrl
+
+    def guard(self, others=(), betas=(0.9, 0.999)):
+        """checks this trainer's gradients (and those of `others`) for inf / NaN and commits the decision for this step on the device:
+        a step with a non-finite gradient neither updates parameters / moments nor advances the step count"""
+        ctrl = self._ctrl()
+        for tr_ in (self, *others):
+            self._ck(self.lib.cddpm_op_grad_check(self.h, _p(tr_.gflat), tr_.gflat.numel(), _p(ctrl), self._s()), "op_grad_check")
+        self._ck(self.lib.cddpm_op_guard_commit(self.h, _p(ctrl), C.c_float(betas[0]), C.c_float(betas[1]), self._s()), "op_guard_commit")
+
+    @property
+    def step_count(self) -> int:
+        """optimizer steps taken (skipped ones do not count); reads the device counter (synchronises)"""
+        return int(self._ctrl()[1].item())
+
+    @property
+    def skipped_steps(self) -> int:
+        return int(self._ctrl()[3].item())
+
+    def adam_step(self, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, grad_scale=None, guarded=False):
         """torch.optim.Adam(lr=1e-4) of DDPM_2D.configure_optimizers (DDPM_2D.py:305-306) on every parameter: one launch over the flat buffers
-        (gradient = gflat / grad_scale), then the convolution images are re-packed from the updated weights"""
+        (gradient = gflat / grad_scale), then the convolution images are re-packed from the updated weights. guarded: `guard()` was already
+        called for this step (jointly with the encoder's gradients); otherwise it is called here."""
         st = self.state
         if "m" not in st:
-            st["m"], st["v"], st["step"] = torch.zeros_like(self.flat), torch.zeros_like(self.flat), 0
-        st["step"] += 1
+            st["m"], st["v"] = torch.zeros_like(self.flat), torch.zeros_like(self.flat)
+        if not guarded:
+            self.guard(betas=betas)
+        st["calls"] = st.get("calls", 0) + 1
         unscale = 1.0 / (grad_scale if grad_scale is not None else self.grad_scale)
-        self._ck(self.lib.cddpm_op_adam(self.h, _p(self.flat), _p(self.gflat), _p(st["m"]), _p(st["v"]), self.flat.numel(), C.c_float(lr),
-                                        C.c_float(betas[0]), C.c_float(betas[1]), C.c_float(eps), st["step"], C.c_float(unscale), self._s()), "op_adam")
+        self._ck(self.lib.cddpm_op_adam_guarded(self.h, _p(self.flat), _p(self.gflat), _p(st["m"]), _p(st["v"]), self.flat.numel(), C.c_float(lr),
+                                                C.c_float(betas[0]), C.c_float(betas[1]), C.c_float(eps), C.c_float(unscale), _p(self._ctrl()),
+                                                self._s()), "op_adam_guarded")
         if self._convs:
-            if self.exp_refresh and st["step"] % self.exp_refresh == 0:
+            if self.exp_refresh and st["calls"] % self.exp_refresh == 0:
                 self.refresh_exponents()
             self.repack()
+
+    # ------------------------------------------------------------------ checkpoint state (Adam moments, step count)
+    def optimizer_state(self) -> Dict[str, torch.Tensor]:
+        """what a checkpoint must carry besides the parameters to resume this optimizer: Adam's m, v (flat, this trainer's layout) and the
+        device control block with the step count"""
+        st = self.state
+        if "m" not in st:
+            st["m"], st["v"] = torch.zeros_like(self.flat), torch.zeros_like(self.flat)
+        return {"m": st["m"].detach().clone(), "v": st["v"].detach().clone(), "ctrl": self._ctrl().detach().clone(),
+                "layout": [(k, int(v.numel())) for k, v in self.p.items()]}
+
+    def load_optimizer_state(self, state) -> None:
+        layout = [(k, int(v.numel())) for k, v in self.p.items()]
+        if [tuple(x) for x in state["layout"]] != layout:
+            raise ValueError("optimizer state was saved for another parameter layout")
+        self.state["m"] = state["m"].to(self.dev, torch.float32).clone()
+        self.state["v"] = state["v"].to(self.dev, torch.float32).clone()
+        self._ctrl().copy_(state["ctrl"].to(self.dev, torch.int32))
+
+    def parameters_changed(self) -> None:
+        """the flat parameter buffer was written from outside (load_state_dict into the aliased module parameters): refresh the
+        pre-scale exponents and the packed convolution images the operators read"""
+        if self._convs:
+            self.refresh_exponents()
+            self.repack()
+
+
+def set_precision(precision) -> int:
+    """selects the arithmetic of the training operators from a Lightning-style precision value: 32 / "32" / "32-true" / None -> fp32-grade
+    (two-term fp16 operand splits); 16 / "16" / "16-mixed" -> plain fp16 operands with fp32 accumulation, the arithmetic of the reference
+    trainer (`precision: 16`, configs/trainer/default.yaml:7). "bf16" / "bf16-mixed" (BASELINE config 5's wording) is served by the same
+    fp16-operand kernels: 11 significand bits instead of bf16's 8, the exponent range covered by the per-tensor power-of-two pre-scales, the
+    loss scale and the non-finite-step guard. Process-wide (include/cddpm.h: cddpm_set_train_precision). Returns the bits in effect."""
+    from . import _lib
+    key = str(precision).lower() if precision is not None else "32"
+    if key in ("32", "32-true", "64", "64-true", "none"):
+        bits = 32
+    elif key in ("16", "16-mixed", "16-true", "bf16", "bf16-mixed", "bf16-true"):
+        bits = 16
+    else:
+        raise ValueError(f"unknown precision {precision!r}")
+    lib = _lib.load_library()
+    if lib.cddpm_set_train_precision(bits) < 0:
+        raise RuntimeError("cddpm_set_train_precision failed")
+    return bits
+
+
+def get_precision() -> int:
+    from . import _lib
+    return int(_lib.load_library().cddpm_get_train_precision())
 
 
 def all_reduce_sum_(flat: torch.Tensor) -> int:
@@ -567,7 +657,9 @@ def training_step(trainer: UNetTrainer, x01: torch.Tensor, cond: Optional[torch.
     world = all_reduce_sum_(trainer.gflat) if all_reduce else 1
     if encoder is not None and all_reduce:
         all_reduce_sum_(encoder.gflat)
-    trainer.adam_step(lr=lr, grad_scale=trainer.grad_scale * world)        # the mean over ranks folds into Adam's unscale factor
+    # one decision for the whole optimizer (after the all-reduce: an inf / NaN on any rank reaches every rank through the sum)
+    trainer.guard(others=(encoder,) if encoder is not None else ())
+    trainer.adam_step(lr=lr, grad_scale=trainer.grad_scale * world, guarded=True)     # the mean over ranks folds into Adam's unscale factor
     if encoder is not None:
-        encoder.adam_step(lr=lr, grad_scale=trainer.grad_scale * world)
+        encoder.adam_step(lr=lr, grad_scale=trainer.grad_scale * world, guarded=True)
     return loss

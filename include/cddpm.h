@@ -306,6 +306,23 @@ int cddpm_op_loss(cddpm_handle h, const float* out_dev, const float* target_dev,
  * g_dev * grad_unscale (1 / the loss scale) */
 int cddpm_op_adam(cddpm_handle h, float* p_dev, const float* g_dev, float* m_dev, float* v_dev, int64_t n, float lr, float beta1, float beta2,
                   float eps, int step, float grad_unscale, void* stream);
+/* The guarded form of the update (what torch's GradScaler does for the reference trainer, `precision: 16` in
+ * configs/trainer/default.yaml:7: a step whose gradients hold inf / NaN is skipped and does not count), entirely on the device.
+ * ctrl_dev: int32[8], zero-initialised by the caller once = {non-finite flag, optimizer step, skip, skipped so far, bits of
+ * 1 - beta1^step, bits of 1 - beta2^step, 0, 0}. Per optimisation step: cddpm_op_grad_check on every gradient buffer (ORs the flag),
+ * ONE cddpm_op_guard_commit (flag set: skip = 1, skipped += 1; else skip = 0, step += 1, bias corrections refreshed; flag cleared),
+ * then cddpm_op_adam_guarded on every parameter buffer (a no-op when skip is set; step and bias corrections come from ctrl_dev). */
+/* Arithmetic of the training operators, process-wide: 32 (default) = fp32-grade products from two-term fp16 splits; 16 = plain fp16
+ * operands with fp32 accumulation in cddpm_op_conv_packed and cddpm_op_conv_wgrad -- what the reference trainer's `precision: 16`
+ * (configs/trainer/default.yaml:7) computes under autocast; GroupNorm, attention, embeddings, Adam and the master weights stay fp32 in both.
+ * Initial value: environment CDDPM_TRAIN_PRECISION (16 | unset). set returns the previous value, -1 for an unsupported `bits`.
+ * The reconstruction entry points are not affected. */
+int cddpm_set_train_precision(int bits);
+int cddpm_get_train_precision(void);
+int cddpm_op_grad_check(cddpm_handle h, const float* g_dev, int64_t n, int32_t* ctrl_dev, void* stream);
+int cddpm_op_guard_commit(cddpm_handle h, int32_t* ctrl_dev, float beta1, float beta2, void* stream);
+int cddpm_op_adam_guarded(cddpm_handle h, float* p_dev, const float* g_dev, float* m_dev, float* v_dev, int64_t n, float lr, float beta1,
+                          float beta2, float eps, float grad_unscale, const int32_t* ctrl_dev, void* stream);
 /* ---- device-resident operator calls (what the training step runs on: no host staging, no synchronisation) ----
  * cddpm_op_set_scratch gives the handle an arena of `bytes` (0: release it) from which the operators of this header take their
  * temporaries instead of a hipMalloc / synchronise / hipFree per call; calls then only enqueue work on `stream` (one stream).

@@ -259,3 +259,100 @@ def test_ddpm2d_validation_step(sd_np, synth):
     assert torch.equal(mod.diffusion.model.state_dict()["out.2.weight"], w0)
     mod.update_prefix("fold1/")
     assert mod.prefix == "fold1/"
+
+
+def _experiment_module(sd_np, synth, **over):
+    M, E = load_pkg("DDPM_2D"), load_pkg("DDPM_encoder")
+    cfg = dict(imageDim=[128, 128, 100], rescaleFactor=2, unet_dim=128, dim_mults=[1, 2, 2], condition=True, test_timesteps=500, timesteps=1000,
+               lr=1e-4, backbone="resnet50", cond_dim=128, objective="pred_x0", loss="l1", noisetype="simplex")
+    cfg.update(over)
+    enc = E.ResNet50Encoder(num_classes=128, in_chans=1)
+    enc.load_state_dict({k: torch.from_numpy(v) for k, v in synth.synth_encoder_state_dict(0).items()}, strict=False)
+    mod = M.DDPM_2D(cfg, encoder=enc)
+    mod.diffusion.model.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()})
+    return mod.cuda()
+
+
+def test_training_step_with_simplex_noise_does_not_touch_the_inference_engine(sd_np, synth, monkeypatch):
+    """the experiment's own training configuration (pred_x0, l1, noisetype simplex: DDPM_cond_spark_2D.yaml): the simplex field of a
+    step is drawn on the TRAINER's handle -- the inference engine (whose packed weights every step invalidates) is neither asked for
+    nor rebuilt while training"""
+    B = load_pkg("backend")
+    mod = _experiment_module(sd_np, synth)
+    gets = []
+    orig = B.HipBackend.get
+    monkeypatch.setattr(B.HipBackend, "get", lambda self, *a, **k: (gets.append(1), orig(self, *a, **k))[1])
+    vol = torch.from_numpy(synth.synth_slices(4, 0, 4, 64, 64)).reshape(4, 1, 64, 64, 1).cuda()
+    np.random.seed(0); torch.manual_seed(0)
+    losses = [float(mod.training_step({"vol": {"data": vol}}, i)["loss"]) for i in range(3)]
+    assert all(np.isfinite(losses)) and gets == [], (losses, len(gets))
+    for name, buf in mod.encoder.named_buffers():
+        if name.endswith("num_batches_tracked"):
+            assert int(buf) == 3
+    mod.reconstruct(vol.squeeze(-1))             # evaluation afterwards: ONE engine (re)build, on the updated weights
+    assert len(gets) >= 1
+
+
+def test_checkpoint_round_trip_resumes_adam(sd_np, synth):
+    """save after two steps (state_dict + the HIP trainers' Adam state through on_save_checkpoint), load into a FRESH module, take the
+    third step there and in the uninterrupted run with the same draws: identical parameters. Without the moments the resumed step would be
+    Adam's first step again (bias correction 1, zero moments) and differ in the fourth digit."""
+    vol = torch.from_numpy(synth.synth_slices(4, 0, 2, 64, 64)).reshape(2, 1, 64, 64, 1).cuda()
+    a = _experiment_module(sd_np, synth)
+    for i in range(2):
+        np.random.seed(10 + i); torch.manual_seed(10 + i)
+        a.training_step({"vol": {"data": vol}}, i)
+    ck = {"state_dict": {k: v.detach().cpu().clone() for k, v in a.state_dict().items()}}
+    a.on_save_checkpoint(ck)
+    assert int(ck["hip_optimizer_state"]["unet"]["ctrl"][1]) == 2 and "encoder" in ck["hip_optimizer_state"]
+    np.random.seed(99); torch.manual_seed(99)
+    a.training_step({"vol": {"data": vol}}, 2)
+    want = {k: v.detach().cpu().clone() for k, v in a.state_dict().items()}
+
+    b = _experiment_module(sd_np, synth)
+    b.load_state_dict(ck["state_dict"])
+    b.on_load_checkpoint(ck)
+    np.random.seed(99); torch.manual_seed(99)
+    b.training_step({"vol": {"data": vol}}, 2)
+    assert b.hip_trainer(vol.device).step_count == 3
+    got = b.state_dict()
+    worst = max(float((got[k].cpu().float() - want[k].float()).abs().max()) for k in want if want[k].is_floating_point())
+    print("resumed vs uninterrupted, third step: max|delta|", worst)
+    assert worst < 1e-6
+    # and WITHOUT the optimizer state the same step lands elsewhere (the test can tell the difference)
+    c = _experiment_module(sd_np, synth)
+    c.load_state_dict(ck["state_dict"])
+    np.random.seed(99); torch.manual_seed(99)
+    c.training_step({"vol": {"data": vol}}, 2)
+    k = "diffusion.model.middle_block.0.in_layers.2.weight"
+    assert float((c.state_dict()[k].cpu() - want[k]).abs().max()) > 2e-5
+
+
+def test_parameters_loaded_or_moved_after_the_trainer_exists(sd_np, synth):
+    """load_state_dict into the aliased parameters re-packs the operators' weight images; module.cpu()/.cuda() (Lightning's teardown)
+    breaks the alias and the next step repairs it, keeping the values the user sees"""
+    vol = torch.from_numpy(synth.synth_slices(4, 0, 2, 64, 64)).reshape(2, 1, 64, 64, 1).cuda()
+    other = {k: torch.from_numpy(v) for k, v in synth.synth_state_dict(3).items()}
+    fresh = _experiment_module(sd_np, synth, noisetype=None)
+    fresh.diffusion.model.load_state_dict(other)
+    torch.manual_seed(5)
+    want = float(fresh.training_step({"vol": {"data": vol}}, 0)["loss"])
+    mod = _experiment_module(sd_np, synth, noisetype=None)
+    torch.manual_seed(4)
+    mod.training_step({"vol": {"data": vol}}, 0)               # trainer exists, packed images built from seed-0 weights
+    mod2 = _experiment_module(sd_np, synth, noisetype=None)    # same start as `fresh`, but the weights arrive AFTER the trainer exists
+    mod2.hip_trainer(vol.device); mod2.hip_encoder_trainer(vol.device)
+    mod2.diffusion.model.load_state_dict(other)
+    torch.manual_seed(5)
+    got = float(mod2.training_step({"vol": {"data": vol}}, 0)["loss"])
+    assert abs(got - want) < 1e-6 * abs(want), (got, want)
+    # broken alias: .cpu() / .cuda() replace param.data
+    w_before = mod.diffusion.model.state_dict()["out.2.weight"].clone()
+    mod = mod.cpu().cuda()
+    assert torch.equal(mod.diffusion.model.state_dict()["out.2.weight"], w_before)
+    torch.manual_seed(6)
+    mod.training_step({"vol": {"data": vol}}, 1)
+    tr_ = mod.hip_trainer(vol.device)
+    p = dict(mod.diffusion.model.named_parameters())["out.2.weight"]
+    assert p.data_ptr() == tr_.p["out.2.weight"].data_ptr()
+    assert float((mod.diffusion.model.state_dict()["out.2.weight"] - w_before).abs().max()) > 1e-6     # the step is visible in state_dict

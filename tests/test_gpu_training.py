@@ -168,3 +168,72 @@ def test_precision16_mode_gradients_are_fp16_grade():
     assert res["finite"] and res["n"] == 316
     assert res["forward_max_abs_err"] < 5e-3 and res["worst"] < 2e-2 and res["median"] < 3e-3
     assert res["median"] > 1e-5          # (the mode is really on: fp32-grade arithmetic gives 2.5e-6 here)
+
+
+def test_a_non_finite_gradient_skips_the_update(synth, sd_np):
+    """the guard of the update (cddpm_op_grad_check / guard_commit / adam_guarded; what torch's GradScaler does for the reference trainer's
+    precision 16): an inf injected into dL/d(out) makes gradients non-finite -> parameters, Adam moments and the step count stay as they
+    were, the skipped counter advances; the next clean step updates normally and counts as step 2."""
+    tr = load_pkg("training")
+    dev = torch.device("cuda", 0)
+    trainer = tr.UNetTrainer({k: torch.from_numpy(v).to(dev) for k, v in sd_np.items()}, device=dev)
+    x01, cond, noise, t = (v.to(dev) for v in _inputs(synth, 2, 32, 32, 1000, 5))
+    tr.training_step(trainer, x01, cond, t=t, noise=noise, lr=1e-4)                      # step 1 (clean)
+    assert trainer.step_count == 1 and trainer.skipped_steps == 0
+    flat1, m1, v1 = trainer.flat.clone(), trainer.state["m"].clone(), trainer.state["v"].clone()
+    x0 = x01 * 2 - 1
+    out = trainer.forward(x0, t, cond)
+    _loss, dout = trainer.loss_and_grad(out, noise, None, "l2")
+    dout[0, 0, 3, 3] = float("inf")
+    trainer.backward(dout)
+    assert not bool(torch.isfinite(trainer.gflat).all())
+    trainer.adam_step(lr=1e-4)
+    assert trainer.step_count == 1 and trainer.skipped_steps == 1
+    assert torch.equal(trainer.flat, flat1) and torch.equal(trainer.state["m"], m1) and torch.equal(trainer.state["v"], v1)
+    tr.training_step(trainer, x01, cond, t=t, noise=noise, lr=1e-4)                      # clean again
+    assert trainer.step_count == 2 and trainer.skipped_steps == 1
+    assert bool(torch.isfinite(trainer.flat).all()) and not torch.equal(trainer.flat, flat1)
+
+
+def test_precision_is_a_runtime_setting(synth, sd_np):
+    """cddpm_set_train_precision: the same process runs a step in the fp32-grade arithmetic and in the reference trainer's precision-16
+    arithmetic (plain fp16 operands, fp32 accumulation); the two losses agree to fp16 grade and differ in the low bits"""
+    tr = load_pkg("training")
+    dev = torch.device("cuda", 0)
+    x01, cond, noise, t = (v.to(dev) for v in _inputs(synth, 2, 32, 32, 1000, 5))
+    losses = {}
+    try:
+        for prec in (32, "16-mixed"):
+            assert tr.set_precision(prec) == (16 if prec != 32 else 32) == tr.get_precision()
+            trainer = tr.UNetTrainer({k: torch.from_numpy(v).to(dev) for k, v in sd_np.items()}, device=dev)
+            losses[prec] = float(tr.training_step(trainer, x01, cond, t=t, noise=noise, objective="pred_noise", loss_type="l2"))
+            trainer.eng.close()
+    finally:
+        tr.set_precision(32)
+    a, b = losses[32], losses["16-mixed"]
+    print("loss fp32-grade", a, "precision 16", b)
+    assert np.isfinite(a) and np.isfinite(b) and a != b and abs(a - b) < 5e-3 * abs(a)
+
+
+def test_training_step_at_config5_share(synth, sd_np):
+    """BASELINE config 5's per-GPU share: ONE optimisation step on 16 x 1 x 128 x 128 (noise-prediction MSE), with the invariants of the
+    path that is verified against float64 autograd at 2 x 32 x 32: finite loss of the expected size, finite gradients, a gradient norm in the
+    range the small case shows, the step counted, parameters moved by ~lr."""
+    tr = load_pkg("training")
+    dev = torch.device("cuda", 0)
+    trainer = tr.UNetTrainer({k: torch.from_numpy(v).to(dev) for k, v in sd_np.items()}, device=dev)
+    x01, cond, noise, t = (v.to(dev) for v in _inputs(synth, 16, 128, 128, 1000, 21))
+    flat0 = trainer.flat.clone()
+    loss = float(tr.training_step(trainer, x01, cond, t=t, noise=noise, objective="pred_noise", loss_type="l2", lr=1e-4))
+    gnorm = float((trainer.gflat.double() / trainer.grad_scale).norm())
+    small = tr.UNetTrainer({k: torch.from_numpy(v).to(dev) for k, v in sd_np.items()}, device=dev)
+    xs, cs, ns, ts = (v.to(dev) for v in _inputs(synth, 2, 32, 32, 1000, 21))
+    loss_s = float(tr.training_step(small, xs, cs, t=ts, noise=ns, objective="pred_noise", loss_type="l2", lr=1e-4))
+    gnorm_s = float((small.gflat.double() / small.grad_scale).norm())
+    print(f"16x128x128: loss {loss:.4f} |g| {gnorm:.4f};  2x32x32: loss {loss_s:.4f} |g| {gnorm_s:.4f}")
+    assert np.isfinite(loss) and 0.2 < loss < 5.0 and 0.2 < loss / loss_s < 5.0
+    assert bool(torch.isfinite(trainer.gflat).all()) and 0.05 < gnorm / gnorm_s < 20.0
+    assert trainer.step_count == 1 and trainer.skipped_steps == 0
+    step = (trainer.flat - flat0).abs()
+    assert 0.5e-4 < float(step.max()) <= 1.01e-4 and float(step.mean()) > 0.3e-4      # Adam's first step: lr * sign(g) wherever g != 0
+    trainer.eng.close(); small.eng.close()
