@@ -329,7 +329,7 @@ class DDPM_2D(_Base):
             # resnet50 default of pre_train_d is 0.05 (spark/Spark_2D.py:277-282, spark/models.py:50, :91-93); plain timm resnet50: 0
             dp = float(_cfg_get(self.cfg, "dp", 0) or 0)
             self._hip_enc_trainer = EncoderTrainer(sd, self.hip_trainer(device), drop_path_rate=(dp if dp != 0 else 0.05) if spark else 0.0)
-            self._enc_core = core
+            self.__dict__["_enc_core"] = core          # NOT a registered submodule: state_dict() must keep the reference's key set
             self._alias_encoder()
             self._load_pending_optimizer_state()
         return self._hip_enc_trainer

@@ -109,7 +109,7 @@ def test_reverse_loop_golden(eng1000, eng50, synth, name, T, start_t, B, H, W, s
     assert float((zdev.cpu() - torch.from_numpy(noise)).abs().max()) < 4e-6
     err2 = np.abs(out2.cpu().numpy() - ref).max()
     print(name, f"device-RNG max|delta| (inputs differ by ulps): {err2:.3e}")
-    assert err2 < 2 * TOL, err2
+    assert err2 < TOL, err2       # north_star's bound holds for the device-RNG path too (its inputs differ from the golden's by ulps)
 
 
 def test_rounding_yardstick_fp64(eng50, synth, oracle, sd_torch):

@@ -172,3 +172,13 @@ def test_precision_mapping(monkeypatch):
     mod = M.DDPM_2D(dict(CFG, precision=16), encoder=torch.nn.Identity())
     assert mod._train_precision() == 16
     assert M.DDPM_2D(CFG, encoder=torch.nn.Identity())._train_precision() is None
+
+
+def test_state_dict_keys_are_the_reference_prefixes_only():
+    """encoder.* / diffusion.model.* / diffusion.<buffers> and nothing else -- also after the training plumbing attached itself"""
+    M = load_pkg("DDPM_2D")
+    mod = M.DDPM_2D(dict(CFG, backbone="resnet50"))
+    mod.__dict__["_enc_core"] = mod.encoder          # what hip_encoder_trainer keeps: must not register a second copy
+    mod._hip_unet_trainer, mod._hip_enc_trainer = None, None
+    keys = list(mod.state_dict())
+    assert all(k.startswith(("encoder.", "diffusion.")) for k in keys), [k for k in keys if not k.startswith(("encoder.", "diffusion."))][:3]
