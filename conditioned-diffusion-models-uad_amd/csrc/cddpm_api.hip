@@ -213,6 +213,20 @@ int plan_ksplit(const cddpm_ctx* h, const ConvArgs& a, short* kbound) {
     return S;
 }
 
+// workgroups of the 128-cout form at the HANDLE's maximum geometry (the quantity both plans are keyed on)
+static long long conv_workgroups_at_max(const cddpm_ctx* h, const ConvArgs& a) {
+    if (h->cur_H <= 0) return 0;
+    const bool up2 = (a.taps == 4);
+    const int Hm = (int)((long long)a.H * h->d.max_h / h->cur_H), Wm = (int)((long long)a.W * h->d.max_w / h->cur_W);
+    const int gh = up2 ? Hm / 2 : Hm, gw = up2 ? Wm / 2 : Wm;
+    return (long long)h->d.max_batch * (up2 ? 4 : 1) * ((gw + 31) / 32) * ((gh + 7) / 8) * (a.Cout / 128);
+}
+static long long conv_workgroups_of_call(const ConvArgs& a) {
+    const bool up2 = (a.taps == 4);
+    const int gh = up2 ? a.H / 2 : a.H, gw = up2 ? a.W / 2 : a.W;
+    return (long long)a.B * (up2 ? 4 : 1) * ((gw + 31) / 32) * ((gh + 7) / 8) * (a.Cout / 128);
+}
+
 int conv_launch(cddpm_ctx* h, ConvArgs a, hipStream_t s) {
     auto it = h->stat_buf.find(a.out);       // outputs that can feed a GroupNorm get their statistics for free
     a.stats = (it != h->stat_buf.end()) ? it->second : nullptr;
@@ -235,6 +249,9 @@ int conv_launch(cddpm_ctx* h, ConvArgs a, hipStream_t s) {
         if (a.stats) h->stat_n[a.out] = nrec_r;
         return 0;
     }
+    // large-batch plan: 256-cout workgroups where the handle's maximum geometry still fills the chip with them (a property of the
+    // handle like S above, never of the call)
+    a.nb2 = conv_nb2_ok(a.Cout, conv_workgroups_at_max(h, a), 1, 0) ? 1 : 0;
     const int nrec = (a.taps == 4) ? conv_stat_records_up2(a.H, a.W) : conv_stat_records(a.H, a.W);
     if (a.stats) {
         // a statically sized buffer against a shape-derived count: refuse to launch rather than write past the end
@@ -1344,6 +1361,7 @@ int cddpm_op_conv_packed(cddpm_handle h, const float* src0, int C0, const float*
     a.stats = stats_dev;       // [B][cddpm_stat_records(H, W, folded_up ? 1 : 0)][Cout][2]: the output's GroupNorm statistics records, for free
     // CDDPM_TRAIN_PRECISION=16: the training operators multiply plain fp16 operands (hi terms only), as the reference trainer's precision 16 does
     a.hi_only = train_precision() == 16 ? 1 : 0;
+    a.nb2 = conv_nb2_ok(a.Cout, conv_workgroups_of_call(a), 1, a.hi_only) ? 1 : 0;      // the training operators plan per call
     launch_conv(a, (hipStream_t)stream);
     HIPCHECK(h, hipGetLastError());
     return 0;
@@ -1396,6 +1414,7 @@ int cddpm_op_conv(cddpm_handle h, const float* src0, int C0, const float* src1, 
     a.coef = coef_dev; a.silu = silu; a.wpk = dw; a.bias = db; a.res = res_dev; a.res_up = res_upsample;
     a.wscale_inv = ldexpf(1.0f, -wexp);
     a.out = out_dev; a.B = B; a.H = H; a.W = W; a.Cout = Cout; a.taps = folded ? 4 : taps;
+    a.nb2 = conv_nb2_ok(a.Cout, conv_workgroups_of_call(a), 1, a.hi_only) ? 1 : 0;
     launch_conv(a, s);
     HIPCHECK(h, hipGetLastError());
     HIPCHECK(h, hipStreamSynchronize(s));
@@ -1431,6 +1450,7 @@ int cddpm_op_conv_skip(cddpm_handle h, const float* src0, int C0, const float* c
     a.skip0 = skip_dev; a.S0 = S0; a.skip_wpk = dws;
     a.wscale_inv = ldexpf(1.0f, -wexp);
     a.out = out_dev; a.B = B; a.H = H; a.W = W; a.Cout = Cout; a.taps = 9;
+    a.nb2 = conv_nb2_ok(a.Cout, conv_workgroups_of_call(a), 1, a.hi_only) ? 1 : 0;
     launch_conv(a, s);
     HIPCHECK(h, hipGetLastError());
     HIPCHECK(h, hipStreamSynchronize(s));
@@ -1465,6 +1485,7 @@ int cddpm_op_conv_gn(cddpm_handle h, const float* src0, int C0, const float* w_h
     a.src0 = src0; a.C0 = C0; a.srcH = H; a.srcW = W; a.wpk = dw; a.bias = db; a.stats = rec;
     a.wscale_inv = ldexpf(1.0f, -wexp);
     a.out = out_dev; a.B = B; a.H = H; a.W = W; a.Cout = Cout; a.taps = 9;
+    a.nb2 = conv_nb2_ok(a.Cout, conv_workgroups_of_call(a), 1, a.hi_only) ? 1 : 0;
     launch_conv(a, s);
     launch_gn_finalize(rec, Cout, nrec, nullptr, 0, 0, B, H * W, g, bt, nullptr, nullptr, 0, 0, nullptr, nullptr, coef_dev, s);
     HIPCHECK(h, hipGetLastError());
@@ -1525,6 +1546,7 @@ int cddpm_op_conv_bench(cddpm_handle h, int C0, int C1, int Cout, int ksize, int
     a.skip0 = sk; a.S0 = skipC; a.skip_wpk = ws;
     a.wscale_inv = ldexpf(1.0f, -bench_wexp);
     a.stamps = nullptr;
+    a.nb2 = conv_nb2_ok(a.Cout, conv_workgroups_of_call(a), 1, 0) ? 1 : 0;
     hipEvent_t e0, e1;
     HIPCHECK(h, hipEventCreate(&e0));
     HIPCHECK(h, hipEventCreate(&e1));
@@ -1598,6 +1620,7 @@ int cddpm_op_conv_dgrad(cddpm_handle h, const float* dy_dev, int Cout, const flo
     a.src0 = dy_dev; a.C0 = Cout; a.srcH = H; a.srcW = W; a.wpk = dw; a.bias = db;
     a.wscale_inv = ldexpf(1.0f, -wexp);
     a.out = dx_dev; a.B = B; a.H = H; a.W = W; a.Cout = Cin; a.taps = taps;
+    a.nb2 = conv_nb2_ok(a.Cout, conv_workgroups_of_call(a), 1, a.hi_only) ? 1 : 0;
     launch_conv(a, s);
     HIPCHECK(h, hipGetLastError());
     HIPCHECK(h, hipStreamSynchronize(s));

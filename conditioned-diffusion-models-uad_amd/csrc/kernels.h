@@ -45,7 +45,11 @@ struct ConvArgs {
     // reference trainer's `precision: 16`; a third of the MFMAs). Set by the training operators under CDDPM_TRAIN_PRECISION=16, never by
     // the reconstruction path.
     int hi_only;
+    // fp16-split family, 16 x 16 form, unsplit K: 1 = workgroups of 256 pixels x 256 couts (two cout blocks per workgroup sharing the
+    // chunk's transformed patch; two-level accumulation, see conv_x6.hip). Decided by the caller with conv_nb2_ok.
+    int nb2;
 };
+bool conv_nb2_ok(int Cout, long long workgroups128, int ksplit, int hi_only);
 // out[b][p][c] = ((plane 0 + plane 1) + ...) + bias[c] + residual, in this fixed order; optional GroupNorm statistics records of
 // `out`: one record per 64 consecutive pixels, [B][ceil(HW / 64)][Cout][2]
 void launch_conv_reduce(const float* planes, int ksplit, const float* bias, const float* res, int res_up, float* out, float* stats,

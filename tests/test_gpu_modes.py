@@ -13,9 +13,11 @@ from conftest import ROOT
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("mode", ["x6", "f32"])
+@pytest.mark.parametrize("mode", ["x6", "f32", "nb2"])
 def test_alternative_conv_family(mode):
-    env = dict(os.environ, CDDPM_CONV=mode)
+    # nb2: the opt-in 256-cout-workgroup plan of the default family (conv_x6.hip, NB = 2: the chunk's patch shared by two cout blocks,
+    # two-level accumulation), forced onto the tests' small shapes
+    env = dict(os.environ, CDDPM_NB2="force") if mode == "nb2" else dict(os.environ, CDDPM_CONV=mode)
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_kernels.py"), "-m", "gpu", "-x", "-q",
                         "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
@@ -39,6 +41,7 @@ out = e.reverse(x.cuda(), cond.cuda(), T, noise=torch.from_numpy(noise).cuda()).
 ref = np.load(os.path.join(%r, "tests", "golden", "loop_B2_32x32_T50_start0.npz"))["out"]
 err = float(np.abs(out - ref).max()); print("ERR", err); assert err < 1e-4, err
 """ % (ROOT, ROOT)
-    for mode in ("x6", "f32"):
-        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, CDDPM_CONV=mode), capture_output=True, text=True, timeout=600)
+    for mode in ("x6", "f32", "nb2"):
+        env = dict(os.environ, CDDPM_NB2="force") if mode == "nb2" else dict(os.environ, CDDPM_CONV=mode)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0 and "ERR" in r.stdout, mode + ": " + r.stdout[-2000:] + r.stderr[-2000:]

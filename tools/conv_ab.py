@@ -96,7 +96,9 @@ def main():
         for r in range(rounds):          # interleaved rounds
             for tag in sys.argv[2:]:
                 lib, _, opt = tag.partition("+")          # "cur+ws": library cur with CDDPM_CONV_WS=1
-                env = dict(os.environ, CDDPM_LIB=os.path.join(CSRC, f"libcddpm_hip_{lib}.so"))
+                env = dict(os.environ, CDDPM_LIB=os.path.join(CSRC, "libcddpm_hip.so" if lib == "prod" else f"libcddpm_hip_{lib}.so"))
+                if opt in ("nb1", "nb2"):          # 256-cout workgroups (conv_x6.hip, NB = 2) off / on wherever the kernel can
+                    env["CDDPM_NB2"] = "0" if opt == "nb1" else "force"
                 if opt == "ws":
                     env["CDDPM_CONV_WS"] = "1"
                 if opt in ("f32", "x6", "h3"):
