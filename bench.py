@@ -38,8 +38,10 @@ Extra objects on the JSON line:
   config.small_batch the reference's real call shape (DDPM_2D.py:193: 4 slices per volume): B = 4, 50 reverse steps.
   config.training_step  BASELINE config 5's per-GPU share (16 x 1 x 128 x 128, noise-prediction MSE, Adam; the context encoder trained jointly,
                 as the reference does): ms per optimisation step on the HIP operators (training.py), 1 warm-up + 3 timed steps.
-  config.training_step_precision16  the same step under CDDPM_TRAIN_PRECISION=16 (plain fp16 operands, fp32 accumulation: the reference
-                trainer's `precision: 16`), in a child process.
+                Carries `precision`, a `training_roofline` object per MFMA operator class (weight-gradient GEMMs; forward + input-gradient
+                convolutions: HIP events on the launch stream over one extra step) and the per-class times of that step.
+  config.training_step_precision16  the same step with precision 16 (plain fp16 operands, fp32 accumulation: the reference trainer's
+                `precision: 16`; selected at run time as the DDPM_2D mirror does from the Trainer's precision).
 """
 from __future__ import annotations
 
@@ -140,26 +142,55 @@ def run_chain(eng, synth, x, n_rev, slice0):
     return x
 
 
-def training_rate(torch, dev, synth, B=16, S=128, steps=3):
-    """one optimisation step (training.training_step: q_sample, UNet forward / backward, encoder forward / backward, Adam) on B x 1 x S x S"""
+def training_rate(torch, dev, synth, B=16, S=128, steps=3, precision=32):
+    """one optimisation step (training.training_step: q_sample, UNet forward / backward, encoder forward / backward, guarded Adam) on
+    B x 1 x S x S, in the arithmetic `precision` selects (32: fp32-grade two-term fp16 splits; 16: plain fp16 operands, fp32 accumulation --
+    the reference trainer's `precision: 16`, configs/trainer/default.yaml:7, which also serves BASELINE config 5's "bf16": see
+    training.set_precision). Then one more step with per-operator HIP events: the training_roofline object."""
     tr, et = importlib.import_module(PKG + ".training"), importlib.import_module(PKG + ".encoder_training")
-    trainer = tr.UNetTrainer({k: torch.from_numpy(v) for k, v in synth.synth_state_dict(0).items()}, device=dev)
-    enc = et.EncoderTrainer({k: torch.from_numpy(v) for k, v in synth.synth_encoder_state_dict(0).items()}, trainer, drop_path_rate=0.05)
-    x01 = torch.from_numpy(synth.synth_slices(1, 0, B, S, S)).reshape(B, 1, S, S).to(dev)
-    noise = torch.from_numpy(synth.noise_xT(1, 0, B, S, S)).reshape(B, 1, S, S).to(dev)
-    t = torch.tensor([(137 * (i + 1)) % 1000 for i in range(B)], dtype=torch.long, device=dev)
-    kw = dict(t=t, noise=noise, objective="pred_noise", loss_type="l2", encoder=enc)
-    losses = [float(tr.training_step(trainer, x01, None, **kw))]
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        loss = tr.training_step(trainer, x01, None, **kw)
-    torch.cuda.synchronize(dev)
-    dt = (time.perf_counter() - t0) / steps
-    losses.append(float(loss))
-    trainer.eng.close()
+    bits = tr.set_precision(precision)
+    try:
+        trainer = tr.UNetTrainer({k: torch.from_numpy(v) for k, v in synth.synth_state_dict(0).items()}, device=dev)
+        enc = et.EncoderTrainer({k: torch.from_numpy(v) for k, v in synth.synth_encoder_state_dict(0).items()}, trainer, drop_path_rate=0.05)
+        x01 = torch.from_numpy(synth.synth_slices(1, 0, B, S, S)).reshape(B, 1, S, S).to(dev)
+        noise = torch.from_numpy(synth.noise_xT(1, 0, B, S, S)).reshape(B, 1, S, S).to(dev)
+        t = torch.tensor([(137 * (i + 1)) % 1000 for i in range(B)], dtype=torch.long, device=dev)
+        kw = dict(t=t, noise=noise, objective="pred_noise", loss_type="l2", encoder=enc)
+        losses = [float(tr.training_step(trainer, x01, None, **kw))]
+        tr.training_step(trainer, x01, None, **kw)             # second warm-up: allocator and scratch arena at their final size
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = tr.training_step(trainer, x01, None, **kw)
+        torch.cuda.synchronize(dev)
+        dt = (time.perf_counter() - t0) / steps
+        losses.append(float(loss))
+        # per-operator-class HIP events over one more step (outside the timed steps)
+        trainer.eng.set_profiling(True)
+        tr.training_step(trainer, x01, None, **kw)
+        torch.cuda.synchronize(dev)
+        trainer.eng.set_profiling(False)
+        prof = trainer.eng.get_profile()
+        skipped = trainer.skipped_steps
+        trainer.eng.close()
+    finally:
+        tr.set_precision(32)
+    nprod = 3.0 if bits == 32 else 1.0                # MFMAs executed per product group: hi*hi + hi*mid + mid*hi, or hi*hi alone
+    roof = {}
+    for cls, what in (("wgrad", "conv weight gradients: k-image passes + fp16 GEMM (conv_wgrad_img_kernel) + partial-tile folds"),
+                      ("conv3x3_mfma", "forward + input-gradient 3x3 convolutions (conv_split_kernel on the forward / transposed image)")):
+        c = prof[cls]
+        if c["ms"] > 0:
+            ach = c["flops"] / (c["ms"] * 1e-3) / 1e12
+            roof[cls] = {"bound": "mfma", "kernel": what, "achieved": nprod * ach, "peak": PEAK_16BIT_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": nprod * ach / PEAK_16BIT_MFMA_TFLOPS, "fp32_equivalent_tflops": ach, "ms_per_step": c["ms"], "launches": c["launches"],
+                         "products_per_multiply": nprod}
+    classes = {k: {"ms_per_step": v["ms"], "launches": v["launches"]} for k, v in prof.items() if v["launches"]}
     return {"workload": f"{B}x1x{S}x{S}, noise-pred MSE, Adam, UNet + context encoder", "ms_per_step": dt * 1e3, "slices_per_s": B / dt,
-            "dtype": "f32_emulated_f16x3 (convolutions), f32 elsewhere", "losses_first_last": losses}
+            "precision": bits, "dtype": ("f32_emulated_f16x3 (convolutions), f32 elsewhere" if bits == 32 else
+                                         "f16 operands with f32 accumulation (convolutions: the reference trainer's precision 16), f32 elsewhere"),
+            "losses_first_last": losses, "skipped_steps": skipped, "training_roofline": roof, "kernel_classes": classes,
+            "profiled_step_ms": sum(v["ms"] for v in prof.values())}
 
 
 def short_rate(torch, dev, B, S, n_rev, warm):
@@ -210,9 +241,60 @@ def self_launch(cmd, env):
     raise SystemExit(0)
 
 
+def residual_workload(args, torch, dev, rank, world, dist, result_fd):
+    """BASELINE.json configs[3] ("full IXI-shaped volume eval: 8192 synthetic 128x128 slices sharded over 8 MI355X, RCCL gather of residual
+    maps"): N slices in contiguous blocks per rank (sharding.shard_range), each rank reconstructs its block in chunks of `--chunk` slices
+    (x_T and z_t drawn on the device, keyed by the GLOBAL slice index) and keeps |x - reconstruction| on the device; ONE all_gather of the
+    residual maps at the end, inside the timed region. value = N / seconds (max over ranks).
+        python bench.py --gpus 8 --workload residual --slices 8192              # the configuration as named (about 12 minutes)
+        python bench.py --workload residual --slices 128 --t-start 50           # a one-GPU smoke of the same code path"""
+    sharding = importlib.import_module(PKG + ".sharding")
+    N, S, chunk = args.slices, args.size, args.chunk
+    eng, synth = make_engine(torch, dev, chunk, S)
+    kw = dict(seed_inputs=4, seed_cond=1, seed_noise=3, t_start=args.t_start, chunk=chunk, gather="all")
+    # warm-up: one small chunk through the same code (kernel first launches, RCCL communicator)
+    sharding.residual_maps_sharded(eng, min(N, 2 * world), S, S, **dict(kw, t_start=min(args.t_start, 5)))
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    res = sharding.residual_maps_sharded(eng, N, S, S, **kw)
+    torch.cuda.synchronize(dev)
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    ok = tuple(res.shape) == (N, 1, S, S) and bool(torch.isfinite(res).all().item()) and bool(((res >= 0) & (res <= 1)).all().item())
+    lo, hi = sharding.shard_range(N, rank, world)
+    out = {"metric": f"residual maps of {S}x{S} slices/sec @ {args.t_start} reverse steps", "value": N / elapsed, "unit": "slices/s",
+           "n_gpus": world, "steps": 1, "warmup": 1, "ms_per_step": elapsed * 1e3, "higher_is_better": True, "scaling": "strong",
+           "vs_baseline": None, "dtype": DTYPE, "data": "synthetic",
+           "config": {"workload": f"configs[3]: {N} synthetic {S}x{S} slices sharded over {world} GPU(s) in contiguous blocks, chunks of {chunk}, "
+                                  f"{args.t_start} reverse steps each, one all_gather of |x - reconstruction| at the end (inside the timed region)",
+                      "slices": N, "slices_this_rank": hi - lo, "chunk": chunk, "t_start": args.t_start, "size": S, "timed_region_s": elapsed,
+                      "conv_family": CONV_MODE, "arithmetic": ARITH, "result_shape": list(res.shape), "finite_and_in_unit_range": ok,
+                      "residual_mean": float(res.mean().item()),
+                      "checksum_first_last": [float(res[0].double().sum().item()), float(res[-1].double().sum().item())]}}
+    eng.close()
+    if rank == 0:
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
+    if dist is not None:
+        dist.destroy_process_group()
+    if not ok:
+        raise SystemExit("bench.py --workload residual: the residual maps are not finite / not in [0,1]")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--workload", default="reverse", choices=("reverse", "residual"),
+                    help="reverse: configs[1] (the headline); residual: configs[3], sharded residual maps + one gather")
+    ap.add_argument("--slices", type=int, default=8192, help="--workload residual: total slices over all ranks")
+    ap.add_argument("--t-start", type=int, default=1000, help="--workload residual: reverse steps per reconstruction")
+    ap.add_argument("--chunk", type=int, default=64, help="--workload residual: slices per cddpm_reverse call")
     ap.add_argument("--steps", type=int, default=20, help="bench steps = segments of 50 reverse steps; 20 = one reconstruction")
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=64, help="slices per GPU (configs[1]: 64)")
@@ -247,7 +329,7 @@ def main():
 
     if args.alt_child:      # one alternative arithmetic family, chosen by CDDPM_CONV in this child's environment
         r = short_rate(torch, dev, B, S, n_rev=10, warm=3)
-        r["conv_family"] = CONV_MODE
+        r["conv_family"] = CONV_MODE + ("_nb2" if os.environ.get("CDDPM_NB2") == "1" else "")
         os.write(result_fd, (json.dumps(r) + "\n").encode())
         return
 
@@ -256,6 +338,9 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)   # RCCL
+
+    if args.workload == "residual":
+        return residual_workload(args, torch, dev, rank, world, dist, result_fd)
 
     slice0 = rank * B                                   # weak scaling: every rank owns B distinct slices
     eng, synth = make_engine(torch, dev, B, S)
@@ -374,12 +459,15 @@ def main():
         out["config"]["small_batch"] = short_rate(torch, dev, 4, S, n_rev=50, warm=10)
         # the strict-fp32 and exact-bf16-split families on the same workload, one child process each
         alts = {}
-        for fam in ("f32", "x6"):
-            if fam == CONV_MODE:
+        for fam in ("f32", "x6", "h3_nb2"):
+            if fam == CONV_MODE or (fam == "h3_nb2" and CONV_MODE != "h3"):
                 continue
             try:
+                # h3_nb2: the default family with 256-cout workgroups (CDDPM_NB2=1; conv_x6.hip NB = 2: faster, two-level accumulation --
+                # opt-in because it costs accuracy at full length)
+                env = dict(os.environ, CDDPM_NB2="1") if fam == "h3_nb2" else dict(os.environ, CDDPM_CONV=fam)
                 r = subprocess.run([sys.executable, os.path.abspath(__file__), "--alt-child", "--batch", str(B), "--size", str(S)],
-                                   env=dict(os.environ, CDDPM_CONV=fam), capture_output=True, text=True, timeout=300)
+                                   env=env, capture_output=True, text=True, timeout=300)
                 alts[fam] = json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else {"error": r.stderr[-300:]}
             except Exception as e:      # the headline does not depend on the side measurements
                 alts[fam] = {"error": repr(e)}
@@ -388,12 +476,8 @@ def main():
             out["config"]["training_step"] = training_rate(torch, dev, synth)
         except Exception as e:
             out["config"]["training_step"] = {"error": repr(e)}
-        try:        # the same step with the reference trainer's precision-16 arithmetic (chosen once per process: a child)
-            r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "train_step_bench.py"), "--batch", "16",
-                                "--encoder", "--steps", "3", "--warmup", "1"], env=dict(os.environ, CDDPM_TRAIN_PRECISION="16"), capture_output=True,
-                               text=True, timeout=300)
-            t16 = json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else {"error": r.stderr[-300:]}
-            out["config"]["training_step_precision16"] = {k: t16[k] for k in ("ms_per_step", "slices_per_s", "losses", "error") if k in t16}
+        try:        # the same step in the reference trainer's precision-16 arithmetic (a runtime setting: cddpm_set_train_precision)
+            out["config"]["training_step_precision16"] = training_rate(torch, dev, synth, precision=16)
         except Exception as e:
             out["config"]["training_step_precision16"] = {"error": repr(e)}
     if rank == 0 and world == 1 and not args.no_cpu:

@@ -146,7 +146,9 @@ int fail(cddpm_ctx* h, const char* fmt, ...) {
     return -1;
 }
 
-enum ProfClass { PC_CONV3 = 0, PC_CONV1 = 1, PC_ATTN = 2, PC_GN = 3, PC_OTHER = 4, PC_COUNT = 5 };
+// 0-4: the reconstruction path's classes; 5-8: the training operators (cddpm_op_*): weight-gradient GEMMs (+ their k-image passes),
+// GroupNorm backward, everything of the context encoder, Adam + guard + weight re-packing
+enum ProfClass { PC_CONV3 = 0, PC_CONV1 = 1, PC_ATTN = 2, PC_GN = 3, PC_OTHER = 4, PC_WGRAD = 5, PC_GNBWD = 6, PC_ENC = 7, PC_OPT = 8, PC_COUNT = 9 };
 
 struct Prof {
     cddpm_ctx* h; hipStream_t s; cddpm_ctx::ProfRec r; bool on;
@@ -1316,6 +1318,7 @@ int cddpm_op_absmax(cddpm_handle h, const float* x_dev, int64_t n, float* out_de
     if (!h) return -1;
     if (!x_dev || !out_dev || n < 1) return fail(h, "cddpm_op_absmax: bad arguments");
     HIPCHECK(h, hipSetDevice(h->device));
+    Prof prof_(h, PC_OPT, 0.0, 0.0, (hipStream_t)stream);
     launch_absmax(x_dev, n, out_dev, (hipStream_t)stream);
     HIPCHECK(h, hipGetLastError());
     return 0;
@@ -1331,6 +1334,7 @@ int cddpm_op_pack_conv(cddpm_handle h, const float* w_dev, int Cout, int Cin, in
         O % 128 || I % 32 || scale_exp < 0 || scale_exp > 24)
         return fail(h, "cddpm_op_pack_conv: unsupported arguments (Cout %d, Cin %d, k %d, mode %d, exponent %d)", Cout, Cin, ksize, mode, scale_exp);
     HIPCHECK(h, hipSetDevice(h->device));
+    Prof prof_(h, PC_OPT, 0.0, 0.0, (hipStream_t)stream);
     launch_pack_conv_split(w_dev, O, I, mode == 2 ? 4 : ksize * ksize, mode, scale_exp, packed_dev, (hipStream_t)stream);
     HIPCHECK(h, hipGetLastError());
     return 0;
@@ -1362,6 +1366,7 @@ int cddpm_op_conv_packed(cddpm_handle h, const float* src0, int C0, const float*
     // CDDPM_TRAIN_PRECISION=16: the training operators multiply plain fp16 operands (hi terms only), as the reference trainer's precision 16 does
     a.hi_only = train_precision() == 16 ? 1 : 0;
     a.nb2 = conv_nb2_ok(a.Cout, conv_workgroups_of_call(a), 1, a.hi_only) ? 1 : 0;      // the training operators plan per call
+    Prof prof_(h, a.taps == 1 ? PC_CONV1 : PC_CONV3, conv_flops(a), conv_bytes(a), (hipStream_t)stream);
     launch_conv(a, (hipStream_t)stream);
     HIPCHECK(h, hipGetLastError());
     return 0;
@@ -1376,6 +1381,7 @@ int cddpm_op_gn_coef_rec(cddpm_handle h, const float* rec0_dev, int n0, int C0, 
     if (!rec0_dev || !gamma_host || !beta_host || !coef_dev) return fail(h, "cddpm_op_gn_coef_rec: NULL argument");
     hipStream_t s = (hipStream_t)stream;
     HIPCHECK(h, hipSetDevice(h->device));
+    Prof prof_(h, PC_GN, 0.0, 0.0, (hipStream_t)stream);
     OpScratch sc(h, s);
     const float* g = sc.param(gamma_host, C);
     const float* bt = sc.param(beta_host, C);
@@ -1576,6 +1582,7 @@ int cddpm_op_gn_coef(cddpm_handle h, const float* src0, int C0, const float* src
         return fail(h, "cddpm_op_gn_coef: unsupported channels (each source <= 1024, together <= %d)", MAX_CONCAT_CHANNELS);
     hipStream_t s = (hipStream_t)stream;
     HIPCHECK(h, hipSetDevice(h->device));
+    Prof prof_(h, PC_GN, 0.0, 0.0, (hipStream_t)stream);
     const int ns = gn_nsplit(B, HW);
     OpScratch sc(h, s);
     float* rec0 = sc.n<float>((size_t)B * ns * C0 * 2);
@@ -1632,6 +1639,7 @@ int cddpm_op_bias_grad(cddpm_handle h, const float* dy_dev, int64_t npix, int C,
     if (!h) return -1;
     if (!dy_dev || !db_dev || npix < 1 || C % 4 || C > 1024) return fail(h, "cddpm_op_bias_grad: bad arguments");
     HIPCHECK(h, hipSetDevice(h->device));
+    Prof prof_(h, PC_OTHER, 0.0, 0.0, (hipStream_t)stream);
     OpScratch sc(h, (hipStream_t)stream);
     double* part = sc.n<double>((size_t)512 * C);
     SCRATCH_CHECK(sc)
@@ -1658,6 +1666,7 @@ int cddpm_op_conv_wgrad(cddpm_handle h, const float* x0_dev, int C0, const float
     const size_t iu = conv_wgrad_image_units(B, H, W, Cin, Cout, taps);
     void* images = iu ? sc.get(iu * 16) : nullptr;
     SCRATCH_CHECK(sc)
+    Prof prof_(h, PC_WGRAD, 2.0 * B * H * W * (double)Cout * Cin * taps, 4.0 * B * (double)H * W * (Cin + Cout), s);
     launch_conv_wgrad(x0_dev, C0, x1_dev, C1, coef_dev, silu, upsample ? 1 : 0, dy_dev, B, H, W, Cout, taps, part, P, images, dw_dev, db_dev, s);
     HIPCHECK(h, hipGetLastError());
     return 0;
@@ -1670,6 +1679,7 @@ int cddpm_op_attention_backward(cddpm_handle h, const float* qkv_dev, const floa
     if (!qkv_dev || !da_dev || !dqkv_dev) return fail(h, "cddpm_op_attention_backward: NULL argument");
     hipStream_t s = (hipStream_t)stream;
     HIPCHECK(h, hipSetDevice(h->device));
+    Prof prof_(h, PC_ATTN, 0.0, 0.0, (hipStream_t)stream);
     static const bool gemm_form = [] { const char* e = getenv("CDDPM_ATTN_BWD"); return e && !strcmp(e, "gemm"); }();
     OpScratch sc(h, s);
     if (gemm_form) {
@@ -1692,6 +1702,7 @@ int cddpm_op_linear_backward(cddpm_handle h, const float* x_dev, const float* w_
     if (M < 1 || N < 1 || K < 1 || !x_dev || !w_dev || !dy_dev || !dw_dev) return fail(h, "cddpm_op_linear_backward: bad arguments");
     hipStream_t s = (hipStream_t)stream;
     HIPCHECK(h, hipSetDevice(h->device));
+    Prof prof_(h, PC_OTHER, 0.0, 0.0, (hipStream_t)stream);
     OpScratch sc(h, s);
     const size_t nscr = linear_backward_scratch_floats(M, N, K, silu_in);
     float* a = nscr ? sc.n<float>(nscr) : nullptr;
@@ -1705,7 +1716,9 @@ int cddpm_op_linear_backward(cddpm_handle h, const float* x_dev, const float* w_
     if (!h) return -1;                                            \
     if (!(cond)) return fail(h, msg);                             \
     hipStream_t s = (hipStream_t)stream;                          \
-    HIPCHECK(h, hipSetDevice(h->device));
+    HIPCHECK(h, hipSetDevice(h->device));                         \
+    Prof prof_(h, PC_OTHER, 0.0, 0.0, s);
+#define OP_CLASS(c, fl) { prof_.r.cls = (c); prof_.r.flops = (fl); }
 #define OP_EPILOGUE()                                             \
     HIPCHECK(h, hipGetLastError());                               \
     return 0;
@@ -1776,6 +1789,7 @@ int cddpm_op_loss(cddpm_handle h, const float* out_dev, const float* target_dev,
 int cddpm_op_adam(cddpm_handle h, float* p_dev, const float* g_dev, float* m_dev, float* v_dev, int64_t n, float lr, float beta1, float beta2,
                   float eps, int step, float grad_unscale, void* stream) {
     OP_PROLOGUE(p_dev && g_dev && m_dev && v_dev && n > 0 && step >= 1, "cddpm_op_adam: bad arguments")
+    OP_CLASS(PC_OPT, 0.0)
     launch_adam(p_dev, g_dev, m_dev, v_dev, n, lr, beta1, beta2, eps, step, grad_unscale, s);
     OP_EPILOGUE()
 }
@@ -1786,17 +1800,20 @@ int cddpm_set_train_precision(int bits) {
 int cddpm_get_train_precision(void) { return train_precision(); }
 int cddpm_op_grad_check(cddpm_handle h, const float* g_dev, int64_t n, int32_t* ctrl_dev, void* stream) {
     OP_PROLOGUE(g_dev && ctrl_dev && n > 0 && ((uintptr_t)g_dev & 15) == 0, "cddpm_op_grad_check: bad arguments (g_dev 16-byte aligned)")
+    OP_CLASS(PC_OPT, 0.0)
     launch_grad_check(g_dev, n, ctrl_dev, s);
     OP_EPILOGUE()
 }
 int cddpm_op_guard_commit(cddpm_handle h, int32_t* ctrl_dev, float beta1, float beta2, void* stream) {
     OP_PROLOGUE(ctrl_dev != nullptr, "cddpm_op_guard_commit: bad arguments")
+    OP_CLASS(PC_OPT, 0.0)
     launch_guard_commit(ctrl_dev, beta1, beta2, s);
     OP_EPILOGUE()
 }
 int cddpm_op_adam_guarded(cddpm_handle h, float* p_dev, const float* g_dev, float* m_dev, float* v_dev, int64_t n, float lr, float beta1,
                           float beta2, float eps, float grad_unscale, const int32_t* ctrl_dev, void* stream) {
     OP_PROLOGUE(p_dev && g_dev && m_dev && v_dev && ctrl_dev && n > 0, "cddpm_op_adam_guarded: bad arguments")
+    OP_CLASS(PC_OPT, 0.0)
     launch_adam_guarded(p_dev, g_dev, m_dev, v_dev, n, lr, beta1, beta2, eps, grad_unscale, ctrl_dev, s);
     OP_EPILOGUE()
 }
@@ -1804,6 +1821,7 @@ int cddpm_op_adam_guarded(cddpm_handle h, float* p_dev, const float* g_dev, floa
 // ---- training-mode operators of the context encoder (encoder_train.hip): NHWC fp32 device tensors ---------------------------------------
 int cddpm_op_enc_pack_w(cddpm_handle h, const float* w_dev, int Cout, int Cin, int K, float* wf_dev, float* wd_dev, void* stream) {
     OP_PROLOGUE(w_dev && wf_dev && Cout > 0 && Cin > 0 && (K == 1 || K == 3), "cddpm_op_enc_pack_w: bad arguments")
+    OP_CLASS(PC_ENC, 0.0)
     launch_enc_pack_w(w_dev, Cout, Cin, K * K, wf_dev, wd_dev, s);
     OP_EPILOGUE()
 }
@@ -1812,6 +1830,7 @@ int cddpm_op_enc_conv(cddpm_handle h, const float* src_dev, const float* w_img_d
     OP_PROLOGUE(src_dev && w_img_dev && dst_dev && B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && (K == 1 || K == 3) && (stride == 1 || stride == 2) &&
                     (transposed ? (Cout % 16 == 0 && Cin % 64 == 0) : (Cin % 16 == 0 && Cout % 64 == 0)),
                 "cddpm_op_enc_conv: unsupported shape (contraction channels a multiple of 16, produced channels of 64; K 1|3, stride 1|2)")
+    OP_CLASS(PC_ENC, 0.0)
     const int Z = enc_conv_split(B, H, W, Cin, Cout, K, stride, transposed);
     OpScratch sc(h, s);
     float* part = nullptr;
@@ -1827,6 +1846,7 @@ int cddpm_op_enc_conv_wgrad(cddpm_handle h, const float* x_dev, const float* dz_
                             int stride, void* stream) {
     OP_PROLOGUE(x_dev && dz_dev && dw_dev && B > 0 && H > 0 && W > 0 && Cin > 0 && Cin % 64 == 0 && Cout > 0 && Cout % 64 == 0 && (K == 1 || K == 3) &&
                     (stride == 1 || stride == 2), "cddpm_op_enc_conv_wgrad: unsupported shape")
+    OP_CLASS(PC_ENC, 0.0)
     const int Ho = (H + stride - 1) / stride, Wo = (W + stride - 1) / stride;
     const int P = enc_wgrad_parts(B, Ho, Wo, Cin, Cout, K);
     OpScratch sc(h, s);
@@ -1837,11 +1857,13 @@ int cddpm_op_enc_conv_wgrad(cddpm_handle h, const float* x_dev, const float* dz_
 }
 int cddpm_op_enc_stem(cddpm_handle h, const float* x_dev, const float* w_dev, float* z_dev, int B, int H, int W, void* stream) {
     OP_PROLOGUE(x_dev && w_dev && z_dev && B > 0 && H > 0 && W > 0, "cddpm_op_enc_stem: bad arguments")
+    OP_CLASS(PC_ENC, 0.0)
     launch_enc_stem_fwd(x_dev, w_dev, z_dev, B, H, W, s);
     OP_EPILOGUE()
 }
 int cddpm_op_enc_stem_wgrad(cddpm_handle h, const float* x_dev, const float* dz_dev, float* dw_dev, int B, int H, int W, void* stream) {
     OP_PROLOGUE(x_dev && dz_dev && dw_dev && B > 0 && H > 0 && W > 0, "cddpm_op_enc_stem_wgrad: bad arguments")
+    OP_CLASS(PC_ENC, 0.0)
     OpScratch sc(h, s);
     double* part = sc.n<double>((size_t)32 * 49 * 64);
     SCRATCH_CHECK(sc)
@@ -1853,6 +1875,7 @@ int cddpm_op_enc_bn_forward(cddpm_handle h, const float* z_dev, const float* gam
                             float* y_dev, int64_t N, int HW, int C, void* stream) {
     OP_PROLOGUE(z_dev && gamma_dev && beta_dev && mean_rstd_dev && y_dev && N > 0 && HW > 0 && C > 0 && C % 64 == 0 && (!run_mean_dev == !run_var_dev),
                 "cddpm_op_enc_bn_forward: bad arguments (C a multiple of 64)")
+    OP_CLASS(PC_ENC, 0.0)
     OpScratch sc(h, s);
     double* part = sc.n<double>((size_t)enc_bn_chunks(N) * 2 * C);
     SCRATCH_CHECK(sc)
@@ -1865,6 +1888,7 @@ int cddpm_op_enc_bn_backward(cddpm_handle h, const float* z_dev, const float* y_
                              float* dbeta_dev, int64_t N, int HW, int C, void* stream) {
     OP_PROLOGUE(z_dev && dy_dev && mean_rstd_dev && gamma_dev && dz_dev && dgamma_dev && dbeta_dev && (!relu || y_dev) && N > 0 && HW > 0 && C > 0 &&
                     C % 64 == 0, "cddpm_op_enc_bn_backward: bad arguments (C a multiple of 64)")
+    OP_CLASS(PC_ENC, 0.0)
     OpScratch sc(h, s);
     double* part = sc.n<double>((size_t)enc_bn_chunks(N) * 2 * C);
     float* k = sc.n<float>((size_t)2 * C);
@@ -1877,12 +1901,14 @@ int cddpm_op_enc_maxpool(cddpm_handle h, const float* x_dev, float* y_dev, int B
                          void* stream) {
     OP_PROLOGUE(x_dev && B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && (backward ? (dy_dev && dx_dev) : (y_dev != nullptr)),
                 "cddpm_op_enc_maxpool: bad arguments")
+    OP_CLASS(PC_ENC, 0.0)
     if (backward) launch_enc_maxpool_backward(x_dev, dy_dev, dx_dev, B, H, W, C, s);
     else launch_enc_maxpool(x_dev, y_dev, B, H, W, C, s);
     OP_EPILOGUE()
 }
 int cddpm_op_enc_avgpool(cddpm_handle h, const float* x_dev, float* g_dev, int B, int HW, int C, int backward, void* stream) {
     OP_PROLOGUE(x_dev && g_dev && B > 0 && HW > 0 && C > 0, "cddpm_op_enc_avgpool: bad arguments")
+    OP_CLASS(PC_ENC, 0.0)
     if (backward) launch_enc_avgpool_backward(x_dev /* dL/dg [B][C] */, g_dev /* dL/dx [B][HW][C] */, B, HW, C, s);
     else launch_enc_avgpool(x_dev, g_dev, B, HW, C, s);
     OP_EPILOGUE()
@@ -1909,6 +1935,7 @@ int cddpm_op_gn_silu_backward(cddpm_handle h, const float* x_dev, const float* x
     float* out_bc = sc.n<float>((size_t)4 * B * C);
     double* part = sc.n<double>((size_t)B * ns * C * 2);
     SCRATCH_CHECK(sc)
+    Prof prof_(h, PC_GNBWD, 0.0, 12.0 * B * (double)HW * C, s);       // reads x and da, writes dx
     if (!rec_dev) launch_gn_partial(x_dev, C, B, HW, ns, rec, s);      // statistics records of x: given (kept from the forward pass) or swept here
     launch_gn_bwd_planes(rec_dev ? rec_dev : rec, rec_dev ? nrec : ns, g, bt, film_dev, B, C, HW, planes, s);
     launch_gn_silu_backward(x_dev, C1 ? x1_dev : nullptr, C - C1, C1 ? dx1_dev : nullptr, da_dev, planes, g, bt, film_dev, silu, B, C, HW, ns, part,
@@ -1942,6 +1969,7 @@ int cddpm_op_attention(cddpm_handle h, const float* qkv_dev, float* out_dev, int
     if (!h) return -1;
     if (C % 64 || N < 1) return fail(h, "cddpm_op_attention: C must be a multiple of 64");
     HIPCHECK(h, hipSetDevice(h->device));
+    Prof prof_(h, PC_ATTN, 0.0, 0.0, (hipStream_t)stream);
     launch_attention(qkv_dev, out_dev, B, N, C, (hipStream_t)stream);
     HIPCHECK(h, hipGetLastError());
     return 0;

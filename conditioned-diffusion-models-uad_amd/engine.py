@@ -244,7 +244,8 @@ class CddpmEngine:
         """clip_denoised of p_sample / ddim_sample (cond_DDPM.py:433, :467) for every later step on this engine"""
         self._ck(self.lib.cddpm_set_clip_denoised(self._h, int(bool(on))), "cddpm_set_clip_denoised")
 
-    PROF_CLASSES = ("conv3x3_mfma", "conv1x1_mfma", "attention", "groupnorm", "other")
+    # 0-4: the reconstruction path; 5-8: the training operators (weight gradients, GroupNorm backward, the context encoder, Adam + re-packing)
+    PROF_CLASSES = ("conv3x3_mfma", "conv1x1_mfma", "attention", "groupnorm", "other", "wgrad", "groupnorm_backward", "encoder", "optimizer")
 
     def set_profiling(self, on: bool):
         self._ck(self.lib.cddpm_set_profiling(self._h, int(on)), "cddpm_set_profiling")
