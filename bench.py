@@ -196,6 +196,8 @@ def training_rate(torch, dev, synth, B=16, S=128, steps=3, precision=32):
 def short_rate(torch, dev, B, S, n_rev, warm):
     """ms per reverse step of a fresh engine at batch B (alt-path children and the small-batch line)"""
     eng, synth = make_engine(torch, dev, B, S)
+    if os.environ.get("CDDPM_BENCH_ACCUM_SWITCH"):            # the opt-in two-level accumulation plan (alt path h3_nb2)
+        eng.set_accumulation_switch(int(os.environ["CDDPM_BENCH_ACCUM_SWITCH"]))
     cond = torch.from_numpy(synth.synth_cond(1, 0, B)).to(dev)
     x = eng.noise_fill(B, S, S, seed=2, stream_id=synth.STREAM_XT, slice0=0)
     eng.prepare_cond(cond, B)
@@ -329,7 +331,7 @@ def main():
 
     if args.alt_child:      # one alternative arithmetic family, chosen by CDDPM_CONV in this child's environment
         r = short_rate(torch, dev, B, S, n_rev=10, warm=3)
-        r["conv_family"] = CONV_MODE + ("_nb2" if os.environ.get("CDDPM_NB2") == "1" else "")
+        r["conv_family"] = CONV_MODE + ("_nb2" if os.environ.get("CDDPM_BENCH_ACCUM_SWITCH") == "0" else "")
         os.write(result_fd, (json.dumps(r) + "\n").encode())
         return
 
@@ -463,9 +465,9 @@ def main():
             if fam == CONV_MODE or (fam == "h3_nb2" and CONV_MODE != "h3"):
                 continue
             try:
-                # h3_nb2: the default family with 256-cout workgroups (CDDPM_NB2=1; conv_x6.hip NB = 2: faster, two-level accumulation --
-                # opt-in because it costs accuracy at full length)
-                env = dict(os.environ, CDDPM_NB2="1") if fam == "h3_nb2" else dict(os.environ, CDDPM_CONV=fam)
+                # h3_nb2: the default family with 256-cout workgroups on every step (cddpm_set_accumulation_switch(0); conv_x6.hip NB = 2:
+                # faster, two-level accumulation -- opt-in because it costs accuracy at full length)
+                env = dict(os.environ, CDDPM_BENCH_ACCUM_SWITCH="0") if fam == "h3_nb2" else dict(os.environ, CDDPM_CONV=fam)
                 r = subprocess.run([sys.executable, os.path.abspath(__file__), "--alt-child", "--batch", str(B), "--size", str(S)],
                                    env=env, capture_output=True, text=True, timeout=300)
                 alts[fam] = json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else {"error": r.stderr[-300:]}

@@ -57,6 +57,7 @@ SYMBOLS = {
     "cddpm_simplex_fill": (_i, [_vp, _fp, _i64, _i, _i, _i, _i, C.c_double, C.c_double, _vp]),
     "cddpm_q_sample": (_i, [_vp, _fp, _fp, _fp, _i, _fp, _fp, _i, _fp, _i, _i, _i, _vp]),
     "cddpm_set_clip_denoised": (_i, [_vp, _i]),
+    "cddpm_set_accumulation_switch": (_i, [_vp, _i]),
     "cddpm_set_profiling": (_i, [_vp, _i]),
     "cddpm_get_profile": (_i, [_vp, _i, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
                                C.POINTER(_i64)]),

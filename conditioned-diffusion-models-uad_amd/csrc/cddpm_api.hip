@@ -94,6 +94,11 @@ struct cddpm_ctx {
     float *qs_sa = nullptr, *qs_s1 = nullptr;
     int objective = 0;
     int clip_denoised = 1;               // cddpm_set_clip_denoised
+    // accumulation plan of the reverse loop (cddpm_set_accumulation_switch; OFF by default): steps t >= nb2_tmin run the Cout = 256
+    // convolutions on 256-cout workgroups (two-level accumulation: faster, ~3x the rounding noise of a convolution), steps below it on
+    // the three-level kernel. nb2_now: whether the forward in flight is such a step (single forwards outside the loop never are).
+    int nb2_tmin = 1 << 30;
+    int nb2_now = 0;
     int* d_t = nullptr;
 
     // workspace
@@ -128,6 +133,7 @@ struct cddpm_ctx {
         hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
         float* img = nullptr; const float* noise = nullptr; uint64_t seed = 0, slice0 = 0; int B = 0, H = 0, W = 0;
         uint64_t gen = 0;
+        int nb2 = 0;                     // the accumulation plan the captured step was planned with
     } sg;
     uint64_t gen = 1;                    // bumped by whatever a captured graph would not see (weights, schedule, taps)
     hipStream_t gstream = nullptr;       // the legacy default stream cannot be captured: graphs run on a stream of the handle
@@ -253,7 +259,7 @@ int conv_launch(cddpm_ctx* h, ConvArgs a, hipStream_t s) {
     }
     // large-batch plan: 256-cout workgroups where the handle's maximum geometry still fills the chip with them (a property of the
     // handle like S above, never of the call)
-    a.nb2 = conv_nb2_ok(a.Cout, conv_workgroups_at_max(h, a), 1, 0) ? 1 : 0;
+    a.nb2 = ((h->nb2_now || conv_nb2_env() == 2) && conv_nb2_ok(a.Cout, conv_workgroups_at_max(h, a), 1, 0)) ? 1 : 0;
     const int nrec = (a.taps == 4) ? conv_stat_records_up2(a.H, a.W) : conv_stat_records(a.H, a.W);
     if (a.stats) {
         // a statically sized buffer against a shape-derived count: refuse to launch rather than write past the end
@@ -1063,7 +1069,10 @@ int cddpm_unet_forward(cddpm_handle h, const float* x_dev, const int32_t* t_dev,
 static int step_once(cddpm_ctx* h, float* img, const float* z_dev, uint64_t seed, uint64_t slice0, int t, int finalize,
                      int B, int H, int W, hipStream_t s) {
     launch_fill_int(h->d_t, B, t, s);
-    if (forward_impl(h, img, h->model_out, B, H, W, s)) return -1;
+    h->nb2_now = (t >= h->nb2_tmin) ? 1 : 0;        // the step's accumulation plan: a function of t alone
+    const int rc_fwd = forward_impl(h, img, h->model_out, B, H, W, s);
+    h->nb2_now = 0;
+    if (rc_fwd) return -1;
     StepArgs a;
     a.x = img; a.model_out = h->model_out; a.t_dev = h->d_t;
     a.coef1 = h->sched[0]; a.coef2 = h->sched[1]; a.logvar = h->sched[2];
@@ -1093,12 +1102,19 @@ static int reverse_by_graph(cddpm_ctx* h, float* img, const float* noise_dev, ui
         HIPCHECK(h, hipEventCreateWithFlags(&h->gev_out, hipEventDisableTiming));
     }
     cddpm_ctx::StepGraph& g = h->sg;
+    if (t_hi >= h->nb2_tmin && t_lo < h->nb2_tmin) {       // the plan switches inside the range: two replays, one graph each
+        if (reverse_by_graph(h, img, noise_dev, seed, slice0, t_hi, h->nb2_tmin, B, H, W, s)) return -1;
+        return reverse_by_graph(h, img, noise_dev, seed, slice0, h->nb2_tmin - 1, t_lo, B, H, W, s);
+    }
+    const int plan = (t_lo >= h->nb2_tmin) ? 1 : 0;
     const bool hit = g.exec && g.img == img && g.noise == noise_dev && g.seed == seed && g.slice0 == slice0 && g.B == B &&
-                     g.H == H && g.W == W && g.gen == h->gen;
+                     g.H == H && g.W == W && g.gen == h->gen && g.nb2 == plan;
     if (!hit) {
         drop_step_graph(h);
         HIPCHECK(h, hipStreamBeginCapture(h->gstream, hipStreamCaptureModeThreadLocal));
+        h->nb2_now = plan;
         int rc = forward_impl(h, img, h->model_out, B, H, W, h->gstream);
+        h->nb2_now = 0;
         StepArgs a;
         a.x = img; a.model_out = h->model_out; a.t_dev = h->d_t;
         a.coef1 = h->sched[0]; a.coef2 = h->sched[1]; a.logvar = h->sched[2];
@@ -1115,7 +1131,7 @@ static int reverse_by_graph(cddpm_ctx* h, float* img, const float* noise_dev, ui
         if (ec != hipSuccess) return fail(h, "hipStreamEndCapture: %s", hipGetErrorString(ec));
         g.graph = graph;
         HIPCHECK(h, hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0));
-        g.img = img; g.noise = noise_dev; g.seed = seed; g.slice0 = slice0; g.B = B; g.H = H; g.W = W; g.gen = h->gen;
+        g.img = img; g.noise = noise_dev; g.seed = seed; g.slice0 = slice0; g.B = B; g.H = H; g.W = W; g.gen = h->gen; g.nb2 = plan;
     }
     HIPCHECK(h, hipEventRecord(h->gev_in, s));
     HIPCHECK(h, hipStreamWaitEvent(h->gstream, h->gev_in, 0));
@@ -1264,6 +1280,13 @@ int cddpm_q_sample(cddpm_handle h, const float* x01_dev, const float* noise_dev,
     return 0;
 }
 
+int cddpm_set_accumulation_switch(cddpm_handle h, int t_switch) {
+    if (!h) return -1;
+    if (t_switch < 0) return fail(h, "cddpm_set_accumulation_switch: t_switch must be >= 0 (>= timesteps: three-level accumulation on every step)");
+    h->nb2_tmin = t_switch;
+    return 0;
+}
+
 int cddpm_set_clip_denoised(cddpm_handle h, int on) {
     if (!h) return -1;
     h->gen++;                            // a captured step graph has the flag baked in
@@ -1365,7 +1388,7 @@ int cddpm_op_conv_packed(cddpm_handle h, const float* src0, int C0, const float*
     a.stats = stats_dev;       // [B][cddpm_stat_records(H, W, folded_up ? 1 : 0)][Cout][2]: the output's GroupNorm statistics records, for free
     // CDDPM_TRAIN_PRECISION=16: the training operators multiply plain fp16 operands (hi terms only), as the reference trainer's precision 16 does
     a.hi_only = train_precision() == 16 ? 1 : 0;
-    a.nb2 = conv_nb2_ok(a.Cout, conv_workgroups_of_call(a), 1, a.hi_only) ? 1 : 0;      // the training operators plan per call
+    a.nb2 = (conv_nb2_env() == 2 && conv_nb2_ok(a.Cout, conv_workgroups_of_call(a), 1, a.hi_only)) ? 1 : 0;      // the training operators plan per call
     Prof prof_(h, a.taps == 1 ? PC_CONV1 : PC_CONV3, conv_flops(a), conv_bytes(a), (hipStream_t)stream);
     launch_conv(a, (hipStream_t)stream);
     HIPCHECK(h, hipGetLastError());
@@ -1420,7 +1443,7 @@ int cddpm_op_conv(cddpm_handle h, const float* src0, int C0, const float* src1, 
     a.coef = coef_dev; a.silu = silu; a.wpk = dw; a.bias = db; a.res = res_dev; a.res_up = res_upsample;
     a.wscale_inv = ldexpf(1.0f, -wexp);
     a.out = out_dev; a.B = B; a.H = H; a.W = W; a.Cout = Cout; a.taps = folded ? 4 : taps;
-    a.nb2 = conv_nb2_ok(a.Cout, conv_workgroups_of_call(a), 1, a.hi_only) ? 1 : 0;
+    a.nb2 = (conv_nb2_env() == 2 && conv_nb2_ok(a.Cout, conv_workgroups_of_call(a), 1, a.hi_only)) ? 1 : 0;
     launch_conv(a, s);
     HIPCHECK(h, hipGetLastError());
     HIPCHECK(h, hipStreamSynchronize(s));
@@ -1456,7 +1479,7 @@ int cddpm_op_conv_skip(cddpm_handle h, const float* src0, int C0, const float* c
     a.skip0 = skip_dev; a.S0 = S0; a.skip_wpk = dws;
     a.wscale_inv = ldexpf(1.0f, -wexp);
     a.out = out_dev; a.B = B; a.H = H; a.W = W; a.Cout = Cout; a.taps = 9;
-    a.nb2 = conv_nb2_ok(a.Cout, conv_workgroups_of_call(a), 1, a.hi_only) ? 1 : 0;
+    a.nb2 = (conv_nb2_env() == 2 && conv_nb2_ok(a.Cout, conv_workgroups_of_call(a), 1, a.hi_only)) ? 1 : 0;
     launch_conv(a, s);
     HIPCHECK(h, hipGetLastError());
     HIPCHECK(h, hipStreamSynchronize(s));
@@ -1491,7 +1514,7 @@ int cddpm_op_conv_gn(cddpm_handle h, const float* src0, int C0, const float* w_h
     a.src0 = src0; a.C0 = C0; a.srcH = H; a.srcW = W; a.wpk = dw; a.bias = db; a.stats = rec;
     a.wscale_inv = ldexpf(1.0f, -wexp);
     a.out = out_dev; a.B = B; a.H = H; a.W = W; a.Cout = Cout; a.taps = 9;
-    a.nb2 = conv_nb2_ok(a.Cout, conv_workgroups_of_call(a), 1, a.hi_only) ? 1 : 0;
+    a.nb2 = (conv_nb2_env() == 2 && conv_nb2_ok(a.Cout, conv_workgroups_of_call(a), 1, a.hi_only)) ? 1 : 0;
     launch_conv(a, s);
     launch_gn_finalize(rec, Cout, nrec, nullptr, 0, 0, B, H * W, g, bt, nullptr, nullptr, 0, 0, nullptr, nullptr, coef_dev, s);
     HIPCHECK(h, hipGetLastError());
@@ -1552,7 +1575,7 @@ int cddpm_op_conv_bench(cddpm_handle h, int C0, int C1, int Cout, int ksize, int
     a.skip0 = sk; a.S0 = skipC; a.skip_wpk = ws;
     a.wscale_inv = ldexpf(1.0f, -bench_wexp);
     a.stamps = nullptr;
-    a.nb2 = conv_nb2_ok(a.Cout, conv_workgroups_of_call(a), 1, 0) ? 1 : 0;
+    a.nb2 = (conv_nb2_env() == 2 && conv_nb2_ok(a.Cout, conv_workgroups_of_call(a), 1, 0)) ? 1 : 0;      // the A/B tool forces it
     hipEvent_t e0, e1;
     HIPCHECK(h, hipEventCreate(&e0));
     HIPCHECK(h, hipEventCreate(&e1));
@@ -1627,7 +1650,7 @@ int cddpm_op_conv_dgrad(cddpm_handle h, const float* dy_dev, int Cout, const flo
     a.src0 = dy_dev; a.C0 = Cout; a.srcH = H; a.srcW = W; a.wpk = dw; a.bias = db;
     a.wscale_inv = ldexpf(1.0f, -wexp);
     a.out = dx_dev; a.B = B; a.H = H; a.W = W; a.Cout = Cin; a.taps = taps;
-    a.nb2 = conv_nb2_ok(a.Cout, conv_workgroups_of_call(a), 1, a.hi_only) ? 1 : 0;
+    a.nb2 = (conv_nb2_env() == 2 && conv_nb2_ok(a.Cout, conv_workgroups_of_call(a), 1, a.hi_only)) ? 1 : 0;
     launch_conv(a, s);
     HIPCHECK(h, hipGetLastError());
     HIPCHECK(h, hipStreamSynchronize(s));

@@ -934,17 +934,19 @@ static void launch_split(const ConvArgs& a, hipStream_t stream) {
     }
 }
 
-// May this launch use 256-cout workgroups (ConvArgs::nb2)? OPT-IN (environment CDDPM_NB2=1; "force": wherever the kernel can, which is how
-// the parity tests run their small shapes through it): measured +9...12 % on every Cout = 256 layer and +6 % on the whole reverse step
-// (DESIGN.md section 4), but its two-level accumulation raises a convolution's rounding noise from 1.9e-7 to ~6e-7 of rms and the
-// full-length chain's deviation from the reference from max 1.5e-4 / rms 7.0e-6 to 2.0e-4 / 1.0e-5 -- worse than the strict-fp32 family
-// (1.6e-4 / 6.6e-6), so the default stays the three-level NB = 1 kernel. With it on: the fp16 16 x 16 family, unsplit K, Cout a multiple of
-// 256, 3x3 / folded 2x2 taps, and `workgroups128` -- the workgroup count of the 128-cout form at the geometry the CALLER plans for (the
-// handle's maximum geometry on the reconstruction path, so that a slice's bits do not depend on the batch it is computed in) -- still
-// fills the chip once halved.
+// May a launch use 256-cout workgroups (ConvArgs::nb2)? Feasibility only -- WHEN it is used is the caller's plan (cddpm_api.hip: the
+// reverse loop uses it for the steps t >= the handle's switch step, see cddpm_set_accumulation_switch): the fp16 16 x 16 family, unsplit
+// K, Cout a multiple of 256, 3x3 / folded 2x2 taps, and `workgroups128` -- the workgroup count of the 128-cout form at the geometry the
+// CALLER plans for (the handle's maximum geometry on the reconstruction path, so that a slice's bits do not depend on the batch it is
+// computed in) -- still fills the chip once halved. Environment CDDPM_NB2: "0" = never; "force" = wherever the kernel can, any geometry,
+// any step and in the operator entry points (how the parity tests run their small shapes through it).
+int conv_nb2_env() {
+    static const int v = [] { const char* e = getenv("CDDPM_NB2"); return (e && e[0] == '0') ? 0 : (e && !strcmp(e, "force")) ? 2 : 1; }();
+    return v;
+}
 bool conv_nb2_ok(int Cout, long long workgroups128, int ksplit, int hi_only) {
-    static const int on = [] { const char* e = getenv("CDDPM_NB2"); return (e && e[0] == '1') ? 1 : (e && !strcmp(e, "force")) ? 2 : 0; }();
     static const bool m16 = [] { const char* e = getenv("CDDPM_M16"); return !(e && e[0] == '0'); }();
+    const int on = conv_nb2_env();
     return on && m16 && conv_mode() == 2 && ksplit <= 1 && !hi_only && (Cout % 256) == 0 && (on == 2 || workgroups128 >= 512);
 }
 

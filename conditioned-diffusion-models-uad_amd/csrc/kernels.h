@@ -50,6 +50,7 @@ struct ConvArgs {
     int nb2;
 };
 bool conv_nb2_ok(int Cout, long long workgroups128, int ksplit, int hi_only);
+int conv_nb2_env();      // CDDPM_NB2: 0 never, 1 by plan (default), 2 forced
 // out[b][p][c] = ((plane 0 + plane 1) + ...) + bias[c] + residual, in this fixed order; optional GroupNorm statistics records of
 // `out`: one record per 64 consecutive pixels, [B][ceil(HW / 64)][Cout][2]
 void launch_conv_reduce(const float* planes, int ksplit, const float* bias, const float* res, int res_up, float* out, float* stats,

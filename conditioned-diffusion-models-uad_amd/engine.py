@@ -240,6 +240,10 @@ class CddpmEngine:
                                          _stream_ptr(self.device)), "cddpm_p_sample")
         return x
 
+    def set_accumulation_switch(self, t_switch: int):
+        """reverse steps t >= t_switch use the faster two-level-accumulation convolution plan (include/cddpm.h); default 200"""
+        self._ck(self.lib.cddpm_set_accumulation_switch(self._h, int(t_switch)), "cddpm_set_accumulation_switch")
+
     def set_clip_denoised(self, on: bool):
         """clip_denoised of p_sample / ddim_sample (cond_DDPM.py:433, :467) for every later step on this engine"""
         self._ck(self.lib.cddpm_set_clip_denoised(self._h, int(bool(on))), "cddpm_set_clip_denoised")

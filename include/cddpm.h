@@ -104,6 +104,20 @@ int cddpm_unet_forward(cddpm_handle h, const float* x_dev, const int32_t* t_dev,
 int cddpm_reverse(cddpm_handle h, float* img_inout_dev, const float* noise_dev, uint64_t seed,
                   uint64_t slice0, int t_start, int B, int H, int W, void* stream);
 
+/* Accumulation plan of the reverse steps (cddpm_p_sample / cddpm_reverse / cddpm_reverse_range; default family, handles whose maximum
+ * geometry gives every Cout = 256 convolution >= 512 workgroups -- i.e. large batches). OPT-IN speed / accuracy trade, off by default
+ * (t_switch = 2^30). Steps t >= t_switch multiply those convolutions on 256-cout workgroups that share the chunk's transformed patch
+ * between two cout blocks and accumulate in two levels: +9...12 % per layer, +6 % per reverse step at B = 64; a convolution's rounding
+ * noise ~6e-7 of rms instead of 1.9e-7 (the reference's CPU fmaf chain: 1.2e-6). Steps t < t_switch use the three-level kernel.
+ * Measured on the full-length parity chain (B = 2 x 128 x 128 x T = 1000, final image vs the reference; tools/accum_switch_sweep.py):
+ *   t_switch   off      500      300      200      0
+ *   max        1.49e-4  1.32e-4  1.59e-4  2.69e-4  1.99e-4
+ *   rms        6.95e-6  8.02e-6  9.08e-6  1.09e-5  1.02e-5        (the reference against itself: 1.02e-4 / 5.6e-6)
+ * -- the extra rounding noise of ANY part of the chain survives to the end (there is no late switch step that hides it), which is why
+ * the default keeps three-level accumulation on every step. A function of t alone: a slice's bits do not depend on its batch.
+ * Single forwards (cddpm_unet_forward, cddpm_ddim_step, the training operators) always use the three-level kernel. */
+int cddpm_set_accumulation_switch(cddpm_handle h, int t_switch);
+
 /* `clip_denoised` of p_sample / ddim_sample (src/models/modules/cond_DDPM.py:433, :467): on (the reference's default, and the
  * handle's) clamps the x0 estimate to [-1,1] before the posterior mean / the DDIM update; off uses it as predicted.
  * Applies to every later cddpm_p_sample / cddpm_reverse / cddpm_reverse_range / cddpm_ddim_step on the handle. */
