@@ -37,7 +37,7 @@ __global__ __launch_bounds__(256) void conv_in1_kernel(const float* __restrict__
         for (int t = 0; t < 9; ++t) wr[i][t] = w[(4 * cq + i) * 9 + t];
     }
     const unsigned total = (unsigned)B * H * W;     // < 2^31 (checked by the launcher): 32-bit divisions, not 64-bit ones
-    const unsigned ppb = 64u * npl;   // pixels per block
+    const unsigned ppb = 16u * npl;   // pixels per block: 16 per thread row (64 made a small batch wait ~45 us on one block's serial loads)
     const unsigned pend = min(total, (blockIdx.x + 1u) * ppb);
     for (unsigned p = blockIdx.x * ppb + pl; p < pend; p += npl) {
         const unsigned row = p / (unsigned)W;
@@ -70,7 +70,7 @@ void launch_conv_in1(const float* x, const float* w, const float* bias, float* o
                      hipStream_t stream) {
     const int npl = 256 / (C / 4);
     const long long total = (long long)B * H * W;
-    const int ppb = 64 * npl;
+    const int ppb = 16 * npl;
     hipLaunchKernelGGL(conv_in1_kernel, dim3((unsigned)((total + ppb - 1) / ppb)), dim3(256), 0, stream, x, w, bias, out,
                        B, H, W, C);
 }

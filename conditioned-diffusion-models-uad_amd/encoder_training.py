@@ -186,7 +186,14 @@ class EncoderTrainer:
         return out
 
     # ------------------------------------------------------------------ backward: dL/d(context) -> gradients of every parameter
-    def backward(self, dcond: torch.Tensor) -> Dict[str, torch.Tensor]:
+    def grad_offset(self, prefix: str) -> int:
+        if not hasattr(self, "_goff"):
+            base = self.gflat.data_ptr()
+            self._goff = {k: (v.data_ptr() - base) // 4 for k, v in self.g.items()}
+        return min((o for k, o in self._goff.items() if k.startswith(prefix)), default=self.gflat.numel())
+
+    def backward(self, dcond: torch.Tensor, buckets=None) -> Dict[str, torch.Tensor]:
+        """buckets (training.GradBuckets): told after every block how much of the flat gradient buffer's tail is final"""
         sv, g = self.saved, self.g
         gap, last = sv["gap"], sv["last"]
         B, Hc, Wc, Cc = last.shape
@@ -216,6 +223,8 @@ class EncoderTrainer:
             else:
                 self.ops.add_(dinp, dsc)
             d = dinp
+            if buckets is not None:
+                buckets.mark_final(self.grad_offset(n + "."))
         a0, z0 = sv["a0"], sv["z0"]
         B, H1, W1, _c = a0.shape
         da0 = torch.empty_like(a0)

@@ -104,6 +104,7 @@ class UNetTrainer:
         emb_names = [n + ".emb_layers.1" for kind, n, _a in self.program if kind == "res" and n + ".emb_layers.1.weight" in params]
         lead = [n + ".weight" for n in emb_names] + [n + ".bias" for n in emb_names]
         names = lead + [k for k in params if k not in set(lead)]
+        self._lead = set(lead)          # written by ONE linear backward at the end of the backward pass (when batched: emb_rows > 0)
         sizes = [(int(params[k].numel()) + 63) // 64 * 64 for k in names]       # 256-byte aligned views
         self.flat = torch.zeros(sum(sizes), dtype=torch.float32, device=self.dev)
         self.gflat = torch.zeros_like(self.flat)
@@ -420,8 +421,18 @@ class UNetTrainer:
         return cur
 
     # ------------------------------------------------------------------ backward: dL/d(model output) -> gradients of every parameter
-    def backward(self, dout: torch.Tensor) -> Dict[str, torch.Tensor]:
-        """fills `g` (views of `gflat`) from dout = grad_scale * dL/d(model output); returns `g`"""
+    def grad_offset(self, prefix: str) -> int:
+        """offset in `gflat` of the first parameter whose name starts with `prefix` (the flat buffer is in forward order: when the backward
+        pass is done with the operator of that name, [offset, end) is final)"""
+        if not hasattr(self, "_goff"):
+            base = self.gflat.data_ptr()
+            self._goff = {k: (v.data_ptr() - base) // 4 for k, v in self.g.items()}
+        batched = self._lead if self.emb_rows else ()
+        return min((o for k, o in self._goff.items() if k.startswith(prefix) and k not in batched), default=self.gflat.numel())
+
+    def backward(self, dout: torch.Tensor, buckets: Optional["GradBuckets"] = None) -> Dict[str, torch.Tensor]:
+        """fills `g` (views of `gflat`) from dout = grad_scale * dL/d(model output); returns `g`. buckets: the gradient exchange, told after
+        every operator how much of the buffer's tail is final (GradBuckets: all-reduce overlapped with the rest of the backward pass)"""
         p, sv, g = self.p, self.saved, self.g
         B, _c, H, W = dout.shape
         dout = dout.contiguous().float()
@@ -494,6 +505,8 @@ class UNetTrainer:
                 self._ck(self.lib.cddpm_op_chan_image_corr(self.h, _p(d), None, 0, _p(sv["x"]), 1, _p(g[name + ".weight"]), B, H, W, self.C, self._s()),
                          "op_chan_image_corr")
                 self._ck(self.lib.cddpm_op_bias_grad(self.h, _p(d), B * H * W, self.C, _p(g[name + ".bias"]), self._s()), "op_bias_grad")
+            if buckets is not None:      # this operator's tensors are final (its emb_layers too unless they are batched at the buffer's head)
+                buckets.mark_final(self.grad_offset(name + "."))
         assert not skip_grads
         if dfilm_all is not None:       # film_all = Linear(SiLU(emb)): dW / db of all 27 emb_layers (contiguous in the gradient buffer) and demb
             emb = sv["emb"]
@@ -618,6 +631,47 @@ def get_precision() -> int:
     return int(_lib.load_library().cddpm_get_train_precision())
 
 
+class GradBuckets:
+    """The data-parallel gradient exchange overlapped with the backward pass (the reference trains under Lightning DDP, src/train.py:62-65:
+    bucketed all-reduce behind autograd hooks). The flat gradient buffer is laid out in FORWARD order and the backward pass fills it from
+    its tail: once the operator that owns offset `lo` has written its gradients, everything in [lo, end) is final. `mark_final(lo)` is
+    called after every backward operator; whenever at least `bucket_floats` finished floats are waiting, their slice is handed to an
+    asynchronous all-reduce (torch.distributed runs it on its own stream behind the kernels already enqueued on the current one, so it
+    overlaps the operators that follow). xGMI rings are per-link bound, so buckets are large (default 8 M floats = 32 MB: the UNet's 176 MB
+    go out in 6 collectives, the last one small). `finish()` flushes the head of the buffer and waits; returns the number of ranks summed
+    over (the caller folds the mean into Adam's unscale factor). Without an initialised process group every call is a no-op."""
+
+    def __init__(self, flat: torch.Tensor, bucket_floats: int = 8 << 20, enabled: bool = True):
+        import torch.distributed as dist
+        self.flat, self.bucket = flat, int(bucket_floats)
+        self.on = bool(enabled) and dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size() if self.on else 1
+        self.hi = flat.numel()            # [hi, end) has been handed to a collective
+        self.lo = flat.numel()            # [lo, end) is final
+        self.work, self.issued = [], []
+
+    def mark_final(self, lo: int):
+        lo = max(0, min(int(lo), self.lo))
+        self.lo = lo
+        if self.on and self.hi - self.lo >= self.bucket:
+            self._issue(self.lo, self.hi)
+
+    def _issue(self, lo: int, hi: int):
+        import torch.distributed as dist
+        if hi > lo:
+            self.work.append(dist.all_reduce(self.flat[lo:hi], async_op=True))
+            self.issued.append((lo, hi))
+            self.hi = lo
+
+    def finish(self) -> int:
+        if self.on:
+            self._issue(0, self.hi)       # whatever is left, head of the buffer included
+            for w in self.work:
+                w.wait()
+        self.work = []
+        return self.world
+
+
 def all_reduce_sum_(flat: torch.Tensor) -> int:
     """the data-parallel gradient exchange (the reference trains under Lightning DDP, src/train.py:62-65): ONE all-reduce over the flat
     gradient buffer (43.9 M floats = 176 MB: a single large ring collective, what xGMI's per-link bandwidth wants). Returns the number of
@@ -651,12 +705,17 @@ def training_step(trainer: UNetTrainer, x01: torch.Tensor, cond: Optional[torch.
     target = noise if objective == "pred_noise" else x0
     p2w = buf["p2_loss_weight"].to(dev)[t].contiguous()
     loss, dout = trainer.loss_and_grad(out, target, p2w, loss_type)
-    trainer.backward(dout)
+    # the gradient exchange runs bucket by bucket BEHIND the backward pass: a bucket's all-reduce is issued as soon as its slice of the
+    # flat buffer is final and overlaps the backward operators that follow (and, for the UNet's last buckets, the encoder's backward)
+    buckets = GradBuckets(trainer.gflat, enabled=all_reduce)
+    trainer.backward(dout, buckets)
+    enc_buckets = None
     if encoder is not None:
-        encoder.backward(trainer.dcond)                    # carries the same loss scale
-    world = all_reduce_sum_(trainer.gflat) if all_reduce else 1
-    if encoder is not None and all_reduce:
-        all_reduce_sum_(encoder.gflat)
+        enc_buckets = GradBuckets(encoder.gflat, enabled=all_reduce)
+        encoder.backward(trainer.dcond, enc_buckets)       # carries the same loss scale
+    world = buckets.finish()
+    if enc_buckets is not None:
+        enc_buckets.finish()
     # one decision for the whole optimizer (after the all-reduce: an inf / NaN on any rank reaches every rank through the sum)
     trainer.guard(others=(encoder,) if encoder is not None else ())
     trainer.adam_step(lr=lr, grad_scale=trainer.grad_scale * world, guarded=True)     # the mean over ranks folds into Adam's unscale factor

@@ -237,3 +237,43 @@ def test_training_step_at_config5_share(synth, sd_np):
     step = (trainer.flat - flat0).abs()
     assert 0.5e-4 < float(step.max()) <= 1.01e-4 and float(step.mean()) > 0.3e-4      # Adam's first step: lr * sign(g) wherever g != 0
     trainer.eng.close(); small.eng.close()
+
+
+def test_gradient_buckets_are_final_when_they_are_handed_to_the_collective(synth, sd_np):
+    """the overlapped gradient exchange (training.GradBuckets) relies on the backward pass filling the flat gradient buffer from its
+    tail: whenever an operator reports `mark_final(lo)`, [lo, end) must not change any more. Recorded here with a stand-in that snapshots the
+    tail at every report and compares it with the buffer after the pass -- for the UNet and for the context encoder."""
+    tr, et = load_pkg("training"), load_pkg("encoder_training")
+    dev = torch.device("cuda", 0)
+    trainer = tr.UNetTrainer({k: torch.from_numpy(v).to(dev) for k, v in sd_np.items()}, device=dev)
+    enc = et.EncoderTrainer({k: torch.from_numpy(v) for k, v in synth.synth_encoder_state_dict(0).items()}, trainer, drop_path_rate=0.0)
+
+    class Recorder:
+        def __init__(self, flat):
+            self.flat, self.marks = flat, []
+
+        def mark_final(self, lo):
+            self.marks.append((int(lo), self.flat[int(lo):].clone()))
+
+    x01, _cond, noise, t = (v.to(dev) for v in _inputs(synth, 2, 64, 64, 1000, 5))
+    cond = enc.forward(x01)
+    x0 = x01 * 2 - 1
+    out = trainer.forward(x0, t, cond)
+    _loss, dout = trainer.loss_and_grad(out, noise, None, "l2")
+    trainer.gflat.fill_(float("nan")); enc.gflat.fill_(float("nan"))
+    ru, re = Recorder(trainer.gflat), Recorder(enc.gflat)
+    trainer.backward(dout, ru)
+    enc.backward(trainer.dcond, re)
+    torch.cuda.synchronize()
+    for rec, n_min in ((ru, 30), (re, 16)):
+        assert len(rec.marks) >= n_min
+        los = [lo for lo, _ in rec.marks]
+        assert los == sorted(los, reverse=True) and los[0] < rec.flat.numel()          # the final region grows from the tail
+        for lo, snap in rec.marks:
+            now = rec.flat[lo:]
+            same = (snap == now) | (torch.isnan(snap) & torch.isnan(now))               # padding between tensors stays NaN-filled
+            assert bool(same.all()), lo
+            assert not bool(torch.isnan(now[: 64]).all())                               # ... and the region really holds gradients
+    # most of the UNet's buffer is final long before the pass ends: the collectives have something to overlap with
+    assert ru.marks[len(ru.marks) // 2][0] < 0.7 * trainer.gflat.numel()
+    trainer.eng.close()

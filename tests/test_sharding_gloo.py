@@ -111,3 +111,44 @@ def test_two_rank_gradient_all_reduce():
     expect = (torch.arange(1000, dtype=torch.float32) * 3).numpy()
     for _rank, n, flat in got:
         assert n == 2 and (flat == expect).all()
+
+
+def _bucket_worker(rank, world, port, q):
+    import importlib
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    tr = importlib.import_module(PKG_NAME + ".training")
+    n = 10_000
+    flat = torch.zeros(n)
+    b = tr.GradBuckets(flat, bucket_floats=3000)
+    # a "backward pass" that finalises the buffer from its tail in uneven pieces; nothing in [lo, end) changes after mark_final(lo)
+    for lo in (9500, 9000, 6100, 6000, 2500, 2400, 100):
+        flat[lo:b.lo] = torch.arange(lo, b.lo, dtype=torch.float32) * (rank + 1)
+        b.mark_final(lo)
+    flat[0:100] = torch.arange(0, 100, dtype=torch.float32) * (rank + 1)       # the head is flushed by finish()
+    world_n = b.finish()
+    q.put((rank, world_n, flat.numpy().copy(), list(b.issued)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_bucketed_all_reduce_behind_the_backward_pass():
+    """training.GradBuckets: slices of the flat gradient buffer are all-reduced (async) as soon as they are final -- the overlapped form
+    of the exchange. Every float is reduced exactly once, buckets hold at least `bucket_floats` (the last one what is left), the result is
+    the plain sum over ranks."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_bucket_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    expect = (torch.arange(10_000, dtype=torch.float32) * 3).numpy()
+    for _rank, n, flat, issued in got:
+        assert n == 2 and (flat == expect).all()
+        assert issued == [(6100, 10000), (2500, 6100), (0, 2500)]            # contiguous, tail first, each >= 3000 floats but the last
