@@ -138,6 +138,8 @@ def make_engine(torch, dev, B, S):
     eng = eng_mod.CddpmEngine(timesteps=T_TOTAL, max_batch=B, max_h=S, max_w=S, device=dev)
     eng.load_weights(synth.synth_state_dict(0))
     eng.set_schedule(sched.schedule_buffers(T_TOTAL))
+    if os.environ.get("CDDPM_BENCH_ACCUM_SWITCH"):            # the opt-in two-level accumulation plan (alt path h3_nb2; profiling runs)
+        eng.set_accumulation_switch(int(os.environ["CDDPM_BENCH_ACCUM_SWITCH"]))
     return eng, synth
 
 
@@ -207,8 +209,6 @@ def training_rate(torch, dev, synth, B=16, S=128, steps=3, precision=32):
 def short_rate(torch, dev, B, S, n_rev, warm):
     """ms per reverse step of a fresh engine at batch B (alt-path children and the small-batch line)"""
     eng, synth = make_engine(torch, dev, B, S)
-    if os.environ.get("CDDPM_BENCH_ACCUM_SWITCH"):            # the opt-in two-level accumulation plan (alt path h3_nb2)
-        eng.set_accumulation_switch(int(os.environ["CDDPM_BENCH_ACCUM_SWITCH"]))
     cond = torch.from_numpy(synth.synth_cond(1, 0, B)).to(dev)
     x = eng.noise_fill(B, S, S, seed=2, stream_id=synth.STREAM_XT, slice0=0)
     eng.prepare_cond(cond, B)
@@ -434,11 +434,13 @@ def main():
         total_ms = sum(v["ms"] for v in prof.values())
         ach = c3["flops"] / (c3["ms"] * 1e-3) / 1e12 if c3["ms"] > 0 else 0.0
         traffic, traffic_src = None, None
-        tfile = os.path.join(ROOT, "profiles", "r02_conv3x3_hbm_traffic.json")
-        if os.path.exists(tfile):
+        import glob
+        tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_conv3x3_hbm_traffic.json")))
+        if tfiles:
             try:
-                traffic = json.load(open(tfile)).get("bytes_per_launch")
-                traffic_src = "profiles/r02_conv3x3_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, builder run; not measured in this run)"
+                traffic = json.load(open(tfiles[-1])).get("bytes_per_launch")
+                traffic_src = (f"profiles/{os.path.basename(tfiles[-1])} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, builder run of the same "
+                               "command; not measured in this run)")
             except Exception:
                 traffic = None
         if CONV_MODE != "f32":

@@ -14,10 +14,11 @@ import sys
 
 root, out = sys.argv[1], sys.argv[2]
 KEY = sys.argv[3] if len(sys.argv) > 3 else "conv_split_kernel<9"
+SUF = sys.argv[4] if len(sys.argv) > 4 else ""         # directory suffix of tools/pmc_passes.sh <suffix>
 
 
 def load(tag):
-    path = os.path.join(root, f"pmc_{tag}", "pmc_counter_collection.csv")
+    path = os.path.join(root, f"pmc{SUF}_{tag}", "pmc_counter_collection.csv")
     per = collections.defaultdict(dict)
     for r in csv.DictReader(open(path)):
         if KEY in r["Kernel_Name"]:
@@ -49,7 +50,7 @@ res["hbm_fetch_bytes_per_launch"] = fetch
 res["hbm_write_bytes_per_launch"] = write
 res["bytes_per_launch"] = fetch + write
 json.dump(res, open(out, "w"), indent=1)
-if KEY.startswith("conv_split_kernel<9"):       # only the headline kernel's run feeds bench.py's roofline.traffic
+if KEY.startswith("conv_split_kernel<9") and not SUF:       # only the headline kernel's default run feeds bench.py's roofline.traffic
   json.dump({"bytes_per_launch": fetch + write, "fetch": fetch, "write": write,
              "note": "rocprofv3 FETCH_SIZE x2 (gfx950 wide-read correction) + WRITE_SIZE, average over the conv3x3 launches of 50 reverse steps, B=64 128x128"},
             open(os.path.join(os.path.dirname(out), os.path.basename(out).split("_")[0] + "_conv3x3_hbm_traffic.json"), "w"), indent=1)
