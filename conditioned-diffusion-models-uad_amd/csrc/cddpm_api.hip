@@ -1388,7 +1388,9 @@ int cddpm_op_conv_packed(cddpm_handle h, const float* src0, int C0, const float*
     a.stats = stats_dev;       // [B][cddpm_stat_records(H, W, folded_up ? 1 : 0)][Cout][2]: the output's GroupNorm statistics records, for free
     // CDDPM_TRAIN_PRECISION=16: the training operators multiply plain fp16 operands (hi terms only), as the reference trainer's precision 16 does
     a.hi_only = train_precision() == 16 ? 1 : 0;
-    a.nb2 = (conv_nb2_env() == 2 && conv_nb2_ok(a.Cout, conv_workgroups_of_call(a), 1, a.hi_only)) ? 1 : 0;      // the training operators plan per call
+    // the training operators plan per call, and DO take the 256-cout workgroups wherever the call fills the chip with them: a gradient's
+    // accuracy need (2e-5 of float64 autograd; SGD noise far above that) is not the 1000-step chain's, and +9...12 % per layer is
+    a.nb2 = (conv_nb2_env() >= 1 && conv_nb2_ok(a.Cout, conv_workgroups_of_call(a), 1, a.hi_only)) ? 1 : 0;
     Prof prof_(h, a.taps == 1 ? PC_CONV1 : PC_CONV3, conv_flops(a), conv_bytes(a), (hipStream_t)stream);
     launch_conv(a, (hipStream_t)stream);
     HIPCHECK(h, hipGetLastError());

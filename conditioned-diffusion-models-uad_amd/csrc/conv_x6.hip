@@ -97,14 +97,9 @@ __global__ __launch_bounds__(64 * ROWS) void conv_split_kernel(const ConvArgs a)
 #ifndef CDDPM_GLDS
 #define CDDPM_GLDS 1
 #endif
-// timing-only ablations (tools/conv_ab.py; results are WRONG with any of them): NOBARRIER no workgroup barriers in the main
-// loop; NOFOLD the accumulators are never read, so the compiler drops the MFMAs and their fragment reads (times everything
-// else); NOFRAG the MFMAs run on registers that are never loaded from LDS; NODMA the weight stages are never copied
-#ifdef CDDPM_ABL_NOBARRIER
-#define LOOP_BARRIER() __builtin_amdgcn_wave_barrier()
-#else
+// (the timing-only ablation builds of rounds 1-2 -- NOBARRIER / NOFOLD / NOFRAG / NODMA, wrong results by construction -- are no longer
+// switches of this file: tools/ubench/conv_x6_ablation_switches.patch re-creates them for tools/conv_ab.py)
 #define LOOP_BARRIER() __syncthreads()
-#endif
     constexpr int FOLD = (TAPS == 9) ? CDDPM_X6_FOLD : (TAPS == 4 ? 2 : 1);   // taps per accumulation group
     constexpr int WSLOTS = 128 * SP;                    // 16-B slots of a weight slab
     // taps per weight stage: the fp16 form stages a whole row of taps (3 of the 3x3, 2 of the folded 2x2) per workgroup
@@ -370,26 +365,16 @@ __global__ __launch_bounds__(64 * ROWS) void conv_split_kernel(const ConvArgs a)
 #pragma unroll
             for (int t16 = 0; t16 < 4; ++t16) {
                 const int off = ((t16 >> 1) * PW + (t16 & 1) * 16) * 8;      // compile-time: an instruction offset
-#ifdef CDDPM_ABL_NOFRAG
-                asm volatile("" : "=v"(fa[0][t16]), "=v"(fa[1][t16]));
-                (void)ah; (void)am; (void)off;
-#else
                 fa[0][t16] = __builtin_bit_cast(f16x8, ah[off]);
                 fa[1][t16] = __builtin_bit_cast(f16x8, am[off]);
-#endif
             }
 #pragma unroll
             for (int nh = 0; nh < 2; ++nh) {            // two cout 16-groups at a time: 12 fragments live instead of 16
                 f16x8 fb[2][2];
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-#ifdef CDDPM_ABL_NOFRAG
-                    asm volatile("" : "=v"(fb[0][j]), "=v"(fb[1][j]));
-                    (void)bh; (void)bm;
-#else
                     fb[0][j] = __builtin_bit_cast(f16x8, bh[128 * (2 * nh + j)]);
                     fb[1][j] = __builtin_bit_cast(f16x8, bm[128 * (2 * nh + j)]);
-#endif
                 }
 #pragma unroll
                 for (int p = 0; p < 3; ++p) {       // mid*hi, hi*mid, hi*hi
@@ -518,10 +503,8 @@ __global__ __launch_bounds__(64 * ROWS) void conv_split_kernel(const ConvArgs a)
 #pragma unroll
         for (int sl = 0; sl < TPS; ++sl)
             if (sl < nsl) {
-#ifndef CDDPM_ABL_NODMA
                 __builtin_amdgcn_global_load_lds((gptr_t)(g0 + sl * WSLOTS), (lptr_t)(d0 + sl * WSLOTS), 16, 0, 0);
                 __builtin_amdgcn_global_load_lds((gptr_t)(g0 + sl * WSLOTS), (lptr_t)(d0 + sl * WSLOTS), 16, 1024, 0);
-#endif
             }
     };
     int nsl_cur = 0;
@@ -597,9 +580,7 @@ __global__ __launch_bounds__(64 * ROWS) void conv_split_kernel(const ConvArgs a)
             nsl_cur = nsl_next;
             STAMP(3)
             if (((st + 1) * TPS) % FOLD == 0 || last_st) {
-#ifndef CDDPM_ABL_NOFOLD
                 fold_acc();
-#endif
                 STAMP(4)
             }
             if (!last_st) {
@@ -638,9 +619,7 @@ __global__ __launch_bounds__(64 * ROWS) void conv_split_kernel(const ConvArgs a)
                 nsl_cur = nsl_next;
                 STAMP(3)
                 if (((st + 1) * TPS) % FOLD == 0 || st == nst - 1) {
-#ifndef CDDPM_ABL_NOFOLD
                     fold_acc();
-#endif
                     STAMP(4)
                 }
                 if (!last_st) {

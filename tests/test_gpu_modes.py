@@ -45,3 +45,12 @@ err = float(np.abs(out - ref).max()); print("ERR", err); assert err < 1e-4, err
         env = dict(os.environ, CDDPM_NB2="force") if mode == "nb2" else dict(os.environ, CDDPM_CONV=mode)
         r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0 and "ERR" in r.stdout, mode + ": " + r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_training_gradients_through_the_256_cout_workgroups():
+    """the training operators use the 256-cout-workgroup convolution (two-level accumulation) wherever a call fills the chip with it; at
+    the gradient test's small shapes only when forced -- loss and all 316 gradients against float64 autograd through it"""
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_training.py"), "-m", "gpu", "-x", "-q", "-k",
+                        "test_loss_and_all_gradients_vs_autograd and 32-32", "-p", "no:cacheprovider"], env=dict(os.environ, CDDPM_NB2="force"),
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
