@@ -112,6 +112,7 @@ SYMBOLS = {
     "cddpm_op_set_scratch": (_i, [_vp, _sz]),
     "cddpm_op_absmax": (_i, [_vp, _fp, _i64, _fp, _vp]),
     "cddpm_op_pack_conv": (_i, [_vp, _fp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "cddpm_op_pack_conv_batch": (_i, [_vp, _vp, _i, _i64, _vp]),
     "cddpm_op_conv_packed": (_i, [_vp, _fp, _i, _fp, _i, _fp, _i, _i, _vp, _i, _fp, _i, _i, _fp, _i, _fp, _i, _fp, _i, _vp, _fp, _fp, _i, _i, _i, _vp]),
     "cddpm_op_gn_coef_rec": (_i, [_vp, _fp, _i, _i, _fp, _i, _i, _fp, _fp, _fp, _fp, _i, _i, _vp]),
     "cddpm_stat_records": (_i, [_i, _i, _i]),

@@ -1363,6 +1363,18 @@ int cddpm_op_pack_conv(cddpm_handle h, const float* w_dev, int Cout, int Cin, in
     return 0;
 }
 
+int cddpm_op_pack_conv_batch(cddpm_handle h, const cddpm_pack_job* jobs_dev, int njobs, int64_t max_units, void* stream) {
+    if (!h) return -1;
+    if (conv_mode() != 2) return fail(h, "cddpm_op_pack_conv_batch: the device packer serves the default convolution family (CDDPM_CONV=h3) only");
+    if (!jobs_dev || njobs < 1 || njobs > 65535 || max_units < 1) return fail(h, "cddpm_op_pack_conv_batch: bad arguments");
+    static_assert(sizeof(cddpm_pack_job) == sizeof(PackJob), "job table layout");
+    HIPCHECK(h, hipSetDevice(h->device));
+    Prof prof_(h, PC_OPT, 0.0, 0.0, (hipStream_t)stream);
+    launch_pack_conv_split_batch(reinterpret_cast<const PackJob*>(jobs_dev), njobs, max_units, (hipStream_t)stream);
+    HIPCHECK(h, hipGetLastError());
+    return 0;
+}
+
 int cddpm_op_conv_packed(cddpm_handle h, const float* src0, int C0, const float* src1, int C1, const float* coef_dev, int silu, int folded_up,
                          const void* packed_dev, int scale_exp, const float* bias_dev, int Cout, int ksize, const float* res_dev,
                          int res_upsample, const float* skip_dev, int S0, const float* skip1_dev, int S1, const void* skip_packed_dev,

@@ -1001,17 +1001,16 @@ void pack_conv_weights_split(const float* w, int Cout, int Cin, int taps, void* 
 //   mode 1 (input gradient)   w[(i O + o) taps + taps - 1 - t]           w = [I][O][k][k]: transposed and flipped
 //   mode 2 (folded upsample)  the class sums of pack_conv_weights_up2 (summed in double, rounded once); w = [O][I][3][3], taps = 4,
 //                             blockIdx.y = class
-__global__ __launch_bounds__(256) void pack_split_kernel(const float* __restrict__ w, int O, int I, int taps, int mode, int wexp,
-                                                         uint16_t* __restrict__ dst) {
+__device__ __forceinline__ void pack_split_unit(const float* __restrict__ w, int O, int I, int taps, int mode, int wexp,
+                                                uint16_t* __restrict__ dst, long long id, int cls_in) {
     const int ncb = O / 128, nch = I / 32;
-    const long long id = (long long)blockIdx.x * 256 + threadIdx.x;
     if (id >= (long long)ncb * nch * taps * 512) return;
     const int u = (int)(id & 3), j = (int)((id >> 2) & 127);
     long long rest = id >> 9;
     const int t = (int)(rest % taps); rest /= taps;
     const int ch = (int)(rest % nch);
     const int cb = (int)(rest / nch);
-    const int cls = blockIdx.y;
+    const int cls = cls_in;
     uint16_t* img = dst + ((((size_t)cls * ncb + cb) * nch + ch) * taps + t) * (size_t)(128 * 8 * 8);
     const int o = cb * 128 + j;
     union { uint16_t q[8]; uint4 v; } hi, mid;
@@ -1039,6 +1038,19 @@ __global__ __launch_bounds__(256) void pack_split_kernel(const float* __restrict
     const int sw = (j >> 1) & 7;
     *reinterpret_cast<uint4*>(img + (size_t)(j * 8 + ((0 + u) ^ sw)) * 8) = hi.v;
     *reinterpret_cast<uint4*>(img + (size_t)(j * 8 + ((4 + u) ^ sw)) * 8) = mid.v;
+}
+__global__ __launch_bounds__(256) void pack_split_kernel(const float* __restrict__ w, int O, int I, int taps, int mode, int wexp,
+                                                         uint16_t* __restrict__ dst) {
+    pack_split_unit(w, O, I, taps, mode, wexp, dst, (long long)blockIdx.x * 256 + threadIdx.x, (int)blockIdx.y);
+}
+// every image of a network in ONE launch: blockIdx.y walks a device table of jobs (a folded-upsample image is four jobs, one per class),
+// blockIdx.x the job's 16-byte units; a job shorter than the grid's x extent leaves its extra workgroups idle
+__global__ __launch_bounds__(256) void pack_split_batch_kernel(const PackJob* __restrict__ jobs) {
+    const PackJob j = jobs[blockIdx.y];
+    pack_split_unit(j.w, j.O, j.I, j.taps, j.mode, j.wexp, static_cast<uint16_t*>(j.dst), (long long)blockIdx.x * 256 + threadIdx.x, j.cls);
+}
+void launch_pack_conv_split_batch(const PackJob* jobs_dev, int njobs, long long max_units, hipStream_t stream) {
+    hipLaunchKernelGGL(pack_split_batch_kernel, dim3((unsigned)((max_units + 255) / 256), (unsigned)njobs), dim3(256), 0, stream, jobs_dev);
 }
 void launch_pack_conv_split(const float* w, int O, int I, int taps, int mode, int wexp, void* dst, hipStream_t stream) {
     const long long n = (long long)(O / 128) * (I / 32) * taps * 512;

@@ -79,6 +79,10 @@ size_t packed_conv_floats(int Cout, int Cin, int taps);
 // device packer of the fp16 two-term family (mode 0 forward, 1 transposed + flipped for the input gradient, 2 folded upsample classes) and
 // max |x| (the power-of-two pre-scale is chosen from it on the host)
 void launch_pack_conv_split(const float* w_dev, int O, int I, int taps, int mode, int wexp, void* dst_dev, hipStream_t stream);
+// one job of the batched device packer: the arguments of launch_pack_conv_split + the folded-upsample class (mode 2: four jobs per image).
+// Layout shared with cddpm_pack_job of include/cddpm.h (40 bytes).
+struct PackJob { const float* w; void* dst; int O, I, taps, mode, wexp, cls; };
+void launch_pack_conv_split_batch(const PackJob* jobs_dev, int njobs, long long max_units, hipStream_t stream);
 void launch_absmax(const float* x, long long n, float* out, hipStream_t stream);
 void pack_conv_weights(const float* w /*[Cout][Cin][k][k]*/, int Cout, int Cin, int taps, float* dst, int wexp);
 // folded weights of nearest-x2-upsample + 3x3: 4 parity classes x 4 taps = 4 * packed_conv_floats(Cout, Cin, 4) floats

@@ -556,6 +556,8 @@ struct ImageArgs {
     int B, H, W, G;
     uint4* img;            // [NS][G][C0 + C1][H * W]
     int NS;
+    float* bsum;           // optional [gridDim.x * G][C0 + C1]: per-workgroup channel sums of the RAW source (the dy image pass: the bias
+                           // gradient's partial sums come for free, the tensor is not read a second time), folded by bias_fold_f32_kernel
 };
 
 __global__ __launch_bounds__(256) void wgrad_image_kernel(const ImageArgs a) {
@@ -563,8 +565,13 @@ __global__ __launch_bounds__(256) void wgrad_image_kernel(const ImageArgs a) {
     const int tid = threadIdx.x, px = tid & 7, q = blockIdx.y * 32 + (tid >> 3), grp = blockIdx.z;
     const int C = a.C0 + a.C1, HW = a.H * a.W;
     const int n = blockIdx.x * 8 + px;
-    if (n >= HW || 4 * q >= C) return;
-    const int y = n / a.W, x = n - y * a.W;
+    if (4 * q >= C) return;                          // (whole groups of 8 lanes leave together)
+    // a ragged last pixel group: its lanes beyond the image stay in the kernel (they take part in the 8-lane sums below with zeros:
+    // the cross-lane steps need every lane of the group at the same instruction) and skip their loads and stores
+    const bool live = n < HW;
+    if (!live && !a.bsum) return;
+    const int nn = live ? n : 0;
+    const int y = nn / a.W, x = nn - y * a.W;
     const int c0 = 4 * q;
     const float* src = (c0 < a.C0) ? a.x0 : a.x1;
     const int Cs = (c0 < a.C0) ? a.C0 : a.C1, cs = (c0 < a.C0) ? c0 : c0 - a.C0;
@@ -574,7 +581,7 @@ __global__ __launch_bounds__(256) void wgrad_image_kernel(const ImageArgs a) {
     for (int i = 0; i < 8; ++i) {
         const int b = grp * 8 + i;
         v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (b < a.B) {
+        if (b < a.B && live) {
             v[i] = *reinterpret_cast<const float4*>(src + ((size_t)(b * sH + sy) * sW + sx) * Cs + cs);
             if (a.coef) {
                 const size_t pl = (size_t)a.B * C, bc = (size_t)b * C + c0;
@@ -586,6 +593,16 @@ __global__ __launch_bounds__(256) void wgrad_image_kernel(const ImageArgs a) {
             if (a.silu) { v[i].x = silu_t(v[i].x); v[i].y = silu_t(v[i].y); v[i].z = silu_t(v[i].z); v[i].w = silu_t(v[i].w); }
         }
     }
+    if (a.bsum) {       // (dy pass: no coefficients, no SiLU -- v holds the raw gradients) sum over the 8 samples, then over the 8 pixels
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { s0 += v[i].x; s1 += v[i].y; s2 += v[i].z; s3 += v[i].w; }
+#pragma unroll
+        for (int m = 1; m < 8; m <<= 1) { s0 += __shfl_xor(s0, m, 8); s1 += __shfl_xor(s1, m, 8); s2 += __shfl_xor(s2, m, 8); s3 += __shfl_xor(s3, m, 8); }
+        if (px == 0)
+            *reinterpret_cast<float4*>(a.bsum + ((size_t)(blockIdx.z * gridDim.x + blockIdx.x)) * C + c0) = make_float4(s0, s1, s2, s3);
+    }
+    if (!live) return;
     const size_t plane = (size_t)a.G * C * HW;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -816,6 +833,21 @@ __global__ __launch_bounds__(256) void bias_grad_fold_kernel(const double* __res
         db[c] = (float)u;
     }
 }
+// the same fold over fp32 partial rows (the rows the dy image pass of the weight gradient leaves behind): db[c] = sum_k part[k][c], fp64
+__global__ __launch_bounds__(256) void bias_fold_f32_kernel(const float* __restrict__ part, int nrow, int C, float* __restrict__ db) {
+    __shared__ double red[16][17];
+    const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4, c = blockIdx.x * 16 + cl;
+    double t = 0;
+    if (c < C)
+        for (int k = sl; k < nrow; k += 16) t += (double)part[(size_t)k * C + c];
+    red[sl][cl] = t;
+    __syncthreads();
+    if (sl == 0 && c < C) {
+        double u = 0;
+        for (int k = 0; k < 16; ++k) u += red[k][cl];
+        db[c] = (float)u;
+    }
+}
 // scratch: nchunk * C doubles, nchunk = bias_grad_chunks(npix, C, scratch floats available)
 int bias_grad_chunks(long long npix, int C, size_t scratch_floats) {
     long long n = (long long)(scratch_floats / 2 / (size_t)C);
@@ -848,7 +880,9 @@ int conv_wgrad_parts(int B, int H, int W, int Cin, int Cout, int taps) {
 size_t conv_wgrad_image_units(int B, int H, int W, int Cin, int Cout, int taps) {
     const int mode = wgrad_mode();
     if (mode == 0 || (taps == 1 && Cin % 64)) return 0;
-    return (size_t)(mode == 2 ? 2 : 1) * ((B + 7) / 8) * (size_t)(Cin + Cout) * H * W;
+    // + the bias gradient's partial rows written by the dy image pass: [(HW / 8 rounded up) * G][Cout] floats
+    const size_t bias_units = ((size_t)((H * W + 7) / 8) * ((B + 7) / 8) * Cout + 3) / 4;
+    return (size_t)(mode == 2 ? 2 : 1) * ((B + 7) / 8) * (size_t)(Cin + Cout) * H * W + bias_units;
 }
 
 void launch_conv_wgrad(const float* x0, int C0, const float* x1, int C1, const float* coef, int silu, int up, const float* dy, int B, int H,
@@ -866,10 +900,16 @@ void launch_conv_wgrad(const float* x0, int C0, const float* x1, int C1, const f
         uint4* dimg = aimg + (size_t)NS * G * Cin * H * W;
         ImageArgs ia;
         ia.x0 = x0; ia.x1 = x1; ia.C0 = C0; ia.C1 = C1; ia.coef = coef; ia.silu = silu; ia.up = up; ia.B = B; ia.H = H; ia.W = W; ia.G = G;
-        ia.img = aimg; ia.NS = NS;
+        ia.img = aimg; ia.NS = NS; ia.bsum = nullptr;
         hipLaunchKernelGGL(wgrad_image_kernel, dim3((H * W + 7) / 8, (Cin + 127) / 128, G), dim3(256), 0, stream, ia);
         ia.x0 = dy; ia.x1 = nullptr; ia.C0 = Cout; ia.C1 = 0; ia.coef = nullptr; ia.silu = 0; ia.up = 0; ia.img = dimg;
+        float* bsum = reinterpret_cast<float*>(dimg + (size_t)NS * G * Cout * H * W);       // behind the two images (conv_wgrad_image_units)
+        ia.bsum = db ? bsum : nullptr;
         hipLaunchKernelGGL(wgrad_image_kernel, dim3((H * W + 7) / 8, (Cout + 127) / 128, G), dim3(256), 0, stream, ia);
+        if (db) {       // the bias gradient from the rows the pass just wrote: dy is not read again
+            hipLaunchKernelGGL(bias_fold_f32_kernel, dim3((Cout + 15) / 16), dim3(256), 0, stream, bsum, ((H * W + 7) / 8) * G, Cout, db);
+            db = nullptr;
+        }
         WgradImgArgs w;
         w.act = aimg; w.dy = dimg; w.Cin = Cin; w.Cout = Cout; w.H = H; w.W = W; w.G = G; w.part = part; w.P = P;
         CK = taps == 9 ? 32 : 64;

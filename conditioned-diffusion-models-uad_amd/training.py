@@ -187,17 +187,35 @@ class UNetTrainer:
         self.wexp = {k: min(raw[j] for j in names if self._convs[j][4] == self._convs[k][4]) for k in names}
 
     def repack(self):
-        """device images of every convolution weight for the forward operator and for the input-gradient operator"""
+        """device images of every convolution weight for the forward operator and for the input-gradient operator: ONE launch over a
+        device table of jobs (cddpm_op_pack_conv_batch; 69 convolutions x 2 operators, a folded-upsample image = four jobs); the table is
+        rebuilt when the pre-scale exponents change"""
+        import numpy as np
         if not hasattr(self, "pk"):
             self.pk, self.pkT = {}, {}
             for k, (co, ci, ks, folded, _g) in self._convs.items():
                 nb = 4 * self.lib.cddpm_packed_conv_bytes(co, ci, 4) if folded else self.lib.cddpm_packed_conv_bytes(co, ci, ks * ks)
                 self.pk[k] = torch.empty(nb, dtype=torch.uint8, device=self.dev)
                 self.pkT[k] = torch.empty(self.lib.cddpm_packed_conv_bytes(ci, co, ks * ks), dtype=torch.uint8, device=self.dev)
-        for k, (co, ci, ks, folded, _g) in self._convs.items():
-            w = self.p[k + ".weight"]
-            self._ck(self.lib.cddpm_op_pack_conv(self.h, _p(w), co, ci, ks, 2 if folded else 0, self.wexp[k], _p(self.pk[k]), self._s()), "op_pack_conv")
-            self._ck(self.lib.cddpm_op_pack_conv(self.h, _p(w), co, ci, ks, 1, self.wexp[k], _p(self.pkT[k]), self._s()), "op_pack_conv")
+            self._jobs_key = None
+        key = tuple(self.wexp[k] for k in self._convs)
+        if self._jobs_key != key:
+            job = np.dtype([("w", "<u8"), ("dst", "<u8"), ("O", "<i4"), ("I", "<i4"), ("taps", "<i4"), ("mode", "<i4"), ("wexp", "<i4"), ("cls", "<i4")])
+            rows = []
+            for k, (co, ci, ks, folded, _g) in self._convs.items():
+                w, e = self.p[k + ".weight"].data_ptr(), self.wexp[k]
+                if folded:
+                    rows += [(w, self.pk[k].data_ptr(), co, ci, 4, 2, e, cls) for cls in range(4)]
+                else:
+                    rows.append((w, self.pk[k].data_ptr(), co, ci, ks * ks, 0, e, 0))
+                rows.append((w, self.pkT[k].data_ptr(), ci, co, ks * ks, 1, e, 0))        # input gradient: the operator's O = Cin, I = Cout
+            tab = np.array(rows, dtype=job)
+            assert tab.itemsize == 40
+            self._jobs = torch.from_numpy(tab.view(np.uint8).copy()).to(self.dev)
+            self._njobs = len(rows)
+            self._job_units = max((r[2] // 128) * (r[3] // 32) * r[4] * 512 for r in rows)
+            self._jobs_key = key
+        self._ck(self.lib.cddpm_op_pack_conv_batch(self.h, _p(self._jobs), self._njobs, self._job_units, self._s()), "op_pack_conv_batch")
 
     # ------------------------------------------------------------------ thin operator wrappers (device pointers in, tensors out)
     def _ck(self, rc, what):

@@ -357,6 +357,12 @@ int cddpm_op_set_scratch(cddpm_handle h, size_t bytes);
 int cddpm_op_absmax(cddpm_handle h, const float* x_dev, int64_t n, float* out_dev, void* stream);
 int cddpm_op_pack_conv(cddpm_handle h, const float* w_dev, int Cout, int Cin, int ksize, int mode, int scale_exp, void* packed_dev,
                        void* stream);
+/* The same packer for MANY images in one launch (the training step re-packs 69 convolutions x 2 operators after every update): a device
+ * table of jobs, each the arguments of cddpm_op_pack_conv with the operator's dimensions resolved -- O / I = output / input channels of
+ * the PACKED operator (mode 1: the forward tensor's Cin / Cout), taps = 1 | 9 (mode 2: 4), cls = the folded-upsample class 0..3 (mode 2:
+ * one job per class, dst the image base; else 0). max_units = the largest O / 128 * I / 32 * taps * 512 over the jobs. */
+typedef struct cddpm_pack_job { const float* w_dev; void* packed_dev; int32_t O, I, taps, mode, scale_exp, cls; } cddpm_pack_job;
+int cddpm_op_pack_conv_batch(cddpm_handle h, const cddpm_pack_job* jobs_dev, int njobs, int64_t max_units, void* stream);
 int cddpm_op_conv_packed(cddpm_handle h, const float* src0_dev, int C0, const float* src1_dev, int C1, const float* coef_dev, int silu,
                          int folded_up, const void* packed_dev, int scale_exp, const float* bias_dev, int Cout, int ksize,
                          const float* res_dev, int res_upsample, const float* skip_dev, int S0, const float* skip1_dev, int S1,

@@ -158,6 +158,31 @@ def test_device_weight_packer_is_the_host_packer(eng, Cout, Cin, k):
         assert np.array_equal(dev.cpu().numpy(), host), (mode, int((dev.cpu().numpy() != host).sum()))
 
 
+def test_batched_device_packer_equals_the_single_image_packer(eng):
+    """cddpm_op_pack_conv_batch (one launch over a device table of jobs: what the training step runs after every update) writes the same
+    bytes as one cddpm_op_pack_conv per image -- forward, input-gradient and the four classes of a folded-upsample image, mixed sizes"""
+    lib = eng.lib
+    torch.manual_seed(7)
+    specs = [(128, 128, 3, 0, 5), (256, 384, 3, 1, 7), (768, 256, 1, 0, 9), (256, 256, 3, 2, 6), (128, 384, 1, 1, 11)]     # Cout, Cin, k, mode, exponent
+    job = np.dtype([("w", "<u8"), ("dst", "<u8"), ("O", "<i4"), ("I", "<i4"), ("taps", "<i4"), ("mode", "<i4"), ("wexp", "<i4"), ("cls", "<i4")])
+    rows, keep, want = [], [], []
+    for Cout, Cin, k, mode, e in specs:
+        w = (torch.randn(Cout, Cin, k, k) * 0.05).cuda().contiguous()
+        O, I = (Cin, Cout) if mode == 1 else (Cout, Cin)
+        taps = 4 if mode == 2 else k * k
+        nb = (4 if mode == 2 else 1) * lib.cddpm_packed_conv_bytes(O, I, taps)
+        single, batched = torch.zeros(nb, dtype=torch.uint8, device="cuda"), torch.zeros(nb, dtype=torch.uint8, device="cuda")
+        assert lib.cddpm_op_pack_conv(eng._h, w.data_ptr(), Cout, Cin, k, mode, e, single.data_ptr(), None) == 0, lib.cddpm_last_error(eng._h)
+        rows += [(w.data_ptr(), batched.data_ptr(), O, I, taps, mode, e, cls) for cls in range(4 if mode == 2 else 1)]
+        keep.append(w); want.append((single, batched))
+    tab = torch.from_numpy(np.array(rows, dtype=job).view(np.uint8).copy()).cuda()
+    units = max((r[2] // 128) * (r[3] // 32) * r[4] * 512 for r in rows)
+    assert lib.cddpm_op_pack_conv_batch(eng._h, tab.data_ptr(), len(rows), units, None) == 0, lib.cddpm_last_error(eng._h)
+    torch.cuda.synchronize()
+    for i, (single, batched) in enumerate(want):
+        assert bool(single.any()) and torch.equal(single, batched), specs[i]
+
+
 @pytest.mark.parametrize("B,C0,Cout,k,H,W,up", [(11, 128, 128, 3, 6, 20, False), (16, 128, 64, 1, 8, 8, False), (9, 128, 128, 3, 8, 16, True),
                                                 (8, 256, 128, 3, 5, 9, False)])
 def test_conv_wgrad_batch_groups_and_ragged_tiles(eng, B, C0, Cout, k, H, W, up):
