@@ -356,3 +356,24 @@ def test_parameters_loaded_or_moved_after_the_trainer_exists(sd_np, synth):
     p = dict(mod.diffusion.model.named_parameters())["out.2.weight"]
     assert p.data_ptr() == tr_.p["out.2.weight"].data_ptr()
     assert float((mod.diffusion.model.state_dict()["out.2.weight"] - w_before).abs().max()) > 1e-6     # the step is visible in state_dict
+
+
+def test_training_step_without_conditioning(synth):
+    """cfg.condition False (the reference's pDDPM-style configuration: no encoder, num_classes None, emb = time_embed(t) alone,
+    OpenAI_Unet.py:583-590, :849-852): the mirror's training step runs on the HIP operators, the loss falls, the weights move"""
+    M = load_pkg("DDPM_2D")
+    cfg = dict(imageDim=[64, 64, 100], rescaleFactor=2, unet_dim=128, dim_mults=[1, 2, 2], condition=False, test_timesteps=500, timesteps=1000,
+               lr=1e-4)
+    mod = M.DDPM_2D(cfg)
+    assert not hasattr(mod, "encoder") and mod.diffusion.model.num_classes is None
+    sd = synth.synth_state_dict(0, num_classes=None)
+    mod.diffusion.model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    mod = mod.cuda()
+    vol = torch.from_numpy(synth.synth_slices(4, 0, 2, 32, 32)).reshape(2, 1, 32, 32, 1).cuda()
+    w0 = mod.diffusion.model.state_dict()["time_embed.2.weight"].clone()
+    torch.manual_seed(0)
+    losses = [float(mod.training_step({"vol": {"data": vol}}, i)["loss"]) for i in range(5)]
+    print("unconditioned training losses", losses)
+    assert all(np.isfinite(losses))
+    assert float((mod.diffusion.model.state_dict()["time_embed.2.weight"] - w0).abs().max()) > 1e-5
+    assert mod.hip_trainer(vol.device).dcond is None
