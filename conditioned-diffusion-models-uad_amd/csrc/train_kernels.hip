@@ -834,18 +834,33 @@ __global__ __launch_bounds__(256) void bias_grad_fold_kernel(const double* __res
     }
 }
 // the same fold over fp32 partial rows (the rows the dy image pass of the weight gradient leaves behind): db[c] = sum_k part[k][c], fp64
-__global__ __launch_bounds__(256) void bias_fold_f32_kernel(const float* __restrict__ part, int nrow, int C, float* __restrict__ db) {
+// blockIdx.y = row range [per * y, per * (y + 1)): out[y][c] (one range: the gradient itself; several: partial rows for a second call)
+__global__ __launch_bounds__(256) void bias_fold_f32_kernel(const float* __restrict__ part, int nrow, int per, int C, float* __restrict__ out) {
     __shared__ double red[16][17];
     const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4, c = blockIdx.x * 16 + cl;
+    const int r0 = per * blockIdx.y, r1 = min(nrow, r0 + per);
     double t = 0;
     if (c < C)
-        for (int k = sl; k < nrow; k += 16) t += (double)part[(size_t)k * C + c];
+        for (int k = r0 + sl; k < r1; k += 16) t += (double)part[(size_t)k * C + c];
     red[sl][cl] = t;
     __syncthreads();
     if (sl == 0 && c < C) {
         double u = 0;
         for (int k = 0; k < 16; ++k) u += red[k][cl];
-        db[c] = (float)u;
+        out[(size_t)blockIdx.y * C + c] = (float)u;
+    }
+}
+// rows -> db in one launch (few rows) or two (row ranges of 128 across workgroups first: a 4096-row fold on C / 16 workgroups took 30 us);
+// `rows` is overwritten by the intermediate partial rows (its first ceil(nrow / 128) rows)
+static void bias_fold_rows(float* rows, int nrow, int C, float* db, hipStream_t stream) {
+    if (nrow > 256) {
+        const int nr = (nrow + 127) / 128;
+        // (the ranges run concurrently: the partial rows go BEHIND the input rows, not over them)
+        float* tmp = rows + (size_t)nrow * C;
+        hipLaunchKernelGGL(bias_fold_f32_kernel, dim3((C + 15) / 16, nr), dim3(256), 0, stream, rows, nrow, 128, C, tmp);
+        hipLaunchKernelGGL(bias_fold_f32_kernel, dim3((C + 15) / 16, 1), dim3(256), 0, stream, tmp, nr, nr, C, db);
+    } else {
+        hipLaunchKernelGGL(bias_fold_f32_kernel, dim3((C + 15) / 16, 1), dim3(256), 0, stream, rows, nrow, nrow, C, db);
     }
 }
 // scratch: nchunk * C doubles, nchunk = bias_grad_chunks(npix, C, scratch floats available)
@@ -881,7 +896,8 @@ size_t conv_wgrad_image_units(int B, int H, int W, int Cin, int Cout, int taps) 
     const int mode = wgrad_mode();
     if (mode == 0 || (taps == 1 && Cin % 64)) return 0;
     // + the bias gradient's partial rows written by the dy image pass: [(HW / 8 rounded up) * G][Cout] floats
-    const size_t bias_units = ((size_t)((H * W + 7) / 8) * ((B + 7) / 8) * Cout + 3) / 4;
+    const size_t bias_rows = (size_t)((H * W + 7) / 8) * ((B + 7) / 8);
+    const size_t bias_units = ((bias_rows + (bias_rows + 127) / 128) * Cout + 3) / 4;       // + the second-level partial rows behind them
     return (size_t)(mode == 2 ? 2 : 1) * ((B + 7) / 8) * (size_t)(Cin + Cout) * H * W + bias_units;
 }
 
@@ -907,7 +923,7 @@ void launch_conv_wgrad(const float* x0, int C0, const float* x1, int C1, const f
         ia.bsum = db ? bsum : nullptr;
         hipLaunchKernelGGL(wgrad_image_kernel, dim3((H * W + 7) / 8, (Cout + 127) / 128, G), dim3(256), 0, stream, ia);
         if (db) {       // the bias gradient from the rows the pass just wrote: dy is not read again
-            hipLaunchKernelGGL(bias_fold_f32_kernel, dim3((Cout + 15) / 16), dim3(256), 0, stream, bsum, ((H * W + 7) / 8) * G, Cout, db);
+            bias_fold_rows(bsum, ((H * W + 7) / 8) * G, Cout, db, stream);
             db = nullptr;
         }
         WgradImgArgs w;
