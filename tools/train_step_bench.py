@@ -66,7 +66,10 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax)
     losses.append(float(loss))
-    res = {"workload": f"training step {B}x1x{S}x{S} (noise-pred MSE, fp32-emulated convolutions, Adam" + (", context encoder trained jointly)" if enc else ")"), "ms_per_step": dt * 1e3,
+    bits = tr.get_precision()
+    arith = "fp32-emulated convolutions" if bits == 32 else "fp16-operand convolutions (precision 16)"
+    res = {"workload": f"training step {B}x1x{S}x{S} (noise-pred MSE, {arith}, Adam" + (", context encoder trained jointly)" if enc else ")"), "ms_per_step": dt * 1e3,
+           "precision": bits,
            "slices_per_s": world * B / dt, "n_gpus": world, "losses": losses, "peak_mem_GB": torch.cuda.max_memory_allocated() / 2 ** 30}
     if a.phases:
         buf = importlib.import_module(PKG + ".schedule").schedule_buffers(T)
