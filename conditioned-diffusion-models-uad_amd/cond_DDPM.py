@@ -17,7 +17,7 @@ Differences, on purpose:
     never assigns it, so its own p_sample crashes; this is the intended semantics (experiment yaml :31);
   * the simplex branch (`noise is not None`, :441-443, :450-452) draws its fields on the device (csrc/simplex.hip,
     bit-exact with the reference's CPU generator for a given seed) instead of numba + host->device copies per step;
-    `box` in-painting is outside the accelerated path and raises NotImplementedError (the reference's `ddim_sample_box` does
+    `box` of p_sample_loop (:455-459) masks x_T as the reference's lines do; `sample(box=...)` raises NotImplementedError (the reference's `ddim_sample_box` does
     not exist, :527); DDIM (`ddim_sample`) is accelerated, with Gaussian or simplex per-step noise as `cfg.noisetype` says;
   * noise: x_T and z_t come from the counter RNG (synth.py / on-device Philox) seeded from torch's global
     generator, so `torch.manual_seed` still makes runs reproducible; pass `seed=`/`slice0=` to pin them.
@@ -46,6 +46,19 @@ def unnormalize_to_zero_to_one(t):
 
 def _extract(a, t, x_shape):
     return a.gather(-1, t).reshape(t.shape[0], *((1,) * (len(x_shape) - 1)))
+
+
+def mask_x_T_to_box(img, box):
+    """The `box` lines of the reference's p_sample_loop (cond_DDPM.py:455-459) AS WRITTEN: a zero tensor receives, sample by sample, the
+    box [x0:x2) x [y1:y3) of `img` -- but `img = img_patch` sits inside that loop, so from the second sample on the copy reads the zero
+    patch itself: sample 0 keeps its x_T inside its box, every other sample starts the chain from all zeros (pinned by a golden made from
+    the reference: tests/golden/box_loop_B3_32x32_T1000_start6.npz). box: [B, 4] rows (x0, y1, x2, y3), tensor or nested list."""
+    img_patch = torch.zeros_like(img)
+    for i in range(img.shape[0]):
+        x0, y1, x2, y3 = (int(v) for v in box[i])
+        img_patch[i, :, y1:y3, x0:x2] = img[i, :, y1:y3, x0:x2]
+        img = img_patch
+    return img
 
 
 class GaussianDiffusion(nn.Module):
@@ -143,8 +156,6 @@ class GaussianDiffusion(nn.Module):
         """Full reverse loop (cond_DDPM.py:446-464): T = num_timesteps if start_t == 0 else start_t, x_T ~ N(0,1),
         T steps, result mapped to [0,1]. Extras: x_T / z_noise ([T,B,1,H,W], z_t at index t) inject given draws,
         seed / slice0 key the counter RNG (slice0 = global index of the first slice, for sharded runs)."""
-        if box is not None:
-            raise NotImplementedError("box in-painting is not part of the cDDPM reconstruction path")
         B, _c, H, W = shape
         dev = torch.device(device) if device is not None else (cond.device if cond is not None else self.betas.device)
         T = self.num_timesteps if start_t == 0 else int(start_t)
@@ -172,6 +183,8 @@ class GaussianDiffusion(nn.Module):
         seed = self._draw_seed(seed)
         if x_T is None:
             x_T = eng.noise_fill(B, H, W, seed=seed, stream_id=_synth.STREAM_XT, slice0=slice0)
+        if box is not None:
+            x_T = mask_x_T_to_box(x_T, box)
         return eng.reverse(x_T, cond.float() if cond is not None else None, T, noise=z_noise, seed=seed, slice0=slice0)
 
     def ddim_time_pairs(self, start_t=0):
@@ -242,9 +255,10 @@ class GaussianDiffusion(nn.Module):
     def sample(self, batch_size=16, cond=None, cond_scale=1., box=None, x_start=None, start_t=0, noise=None, **kw):
         """(cond_DDPM.py:517-530) image_size may be an int or an (H, W) pair, as DDPM_2D passes it."""
         hw = self.image_size if isinstance(self.image_size, (tuple, list)) else (self.image_size, self.image_size)
+        if box is not None:          # the reference routes EVERY box call of sample() to ddim_sample_box (:526-528), which does not exist
+            raise NotImplementedError("sample(box=...): ddim_sample_box is undefined in the reference (cond_DDPM.py:527); "
+                                      "p_sample_loop(box=...) is the branch that exists")
         if self.is_ddim_sampling:
-            if box is not None:
-                raise NotImplementedError("box in-painting (ddim_sample_box is undefined in the reference, :527)")
             return self.ddim_sample((batch_size, self.channels, int(hw[0]), int(hw[1])), cond=cond, cond_scale=cond_scale,
                                     x_start=x_start, start_t=start_t, noise=noise, **kw)
         return self.p_sample_loop((batch_size, self.channels, int(hw[0]), int(hw[1])), cond=cond, cond_scale=cond_scale,

@@ -1,0 +1,58 @@
+"""ORACLE tooling -- build-container only: the `box` branch of the REFERENCE's p_sample_loop (cond_DDPM.py:455-459), imported from
+/root/reference by ref_harness.py.
+
+    python oracle/make_golden_box.py            # seconds
+
+What the reference's lines do, as written: `img_patch` starts as zeros; for sample i the box [x0:x2) x [y1:y3) of `img` is copied into
+it -- and `img = img_patch` INSIDE the loop, so from the second sample on the copy reads the (zero) patch itself: sample 0 keeps its
+x_T inside its box, every other sample starts from all zeros. The mirror reproduces exactly that (cond_DDPM.mask_x_T_to_box); this
+script stores the reference's output so the behaviour is pinned, quirk included. box rows are (x0, y1, x2, y3).
+Outputs only: tests/golden/box_loop_B3_32x32_T1000_start6.npz + a MANIFEST.json entry."""
+from __future__ import annotations
+
+import importlib
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+synth = importlib.import_module("conditioned-diffusion-models-uad_amd.synth")
+import cddpm_oracle as O  # noqa: E402
+import ref_harness as R  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+NAME = "box_loop_B3_32x32_T1000_start6"
+BOX = [[4, 6, 20, 26], [0, 0, 32, 32], [10, 3, 31, 17]]
+
+
+def main():
+    B, H, W, T, start_t = 3, 32, 32, 1000, 6
+    sd = O.to_torch_sd(synth.synth_state_dict(0))
+    _m, diff = R.build_reference(sd, image_size=(H, W), timesteps=T)
+    cond = torch.from_numpy(synth.synth_cond(1, 0, B))
+    xT = torch.from_numpy(synth.noise_xT(2, 0, B, H, W))
+    zs = {t: torch.from_numpy(synth.noise_z(3, t, 0, B, H, W)) for t in range(1, start_t)}
+    box = torch.tensor(BOX, dtype=torch.long)
+    with R.injected_randn([xT] + [zs[t] for t in range(start_t - 1, 0, -1)]):
+        ref = diff.p_sample_loop((B, 1, H, W), cond=cond, start_t=start_t, box=box)
+    # the oracle on the masked x_T the reference's lines produce
+    masked = torch.zeros_like(xT)
+    masked[0, :, BOX[0][1]:BOX[0][3], BOX[0][0]:BOX[0][2]] = xT[0, :, BOX[0][1]:BOX[0][3], BOX[0][0]:BOX[0][2]]
+    ora = O.p_sample_loop(masked, cond, sd, O.schedule_buffers(T), lambda t: zs[t], start_t=start_t)
+    err = float((ref - ora).abs().max())
+    np.savez_compressed(os.path.join(GOLD, NAME + ".npz"), out=ref.numpy(), box=np.array(BOX, np.int64))
+    mpath = os.path.join(GOLD, "MANIFEST.json")
+    man = json.load(open(mpath))
+    man["cases"][NAME] = dict(B=B, H=H, W=W, timesteps=T, start_t=start_t, box=BOX, oracle_vs_reference_maxabs=err,
+                              seeds=dict(weights=0, cond=1, xT=2, z=3))
+    json.dump(man, open(mpath, "w"), indent=1, sort_keys=True)
+    print(NAME, "oracle (on the masked x_T) vs reference:", err)
+
+
+if __name__ == "__main__":
+    main()

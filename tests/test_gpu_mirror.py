@@ -377,3 +377,19 @@ def test_training_step_without_conditioning(synth):
     assert all(np.isfinite(losses))
     assert float((mod.diffusion.model.state_dict()["time_embed.2.weight"] - w0).abs().max()) > 1e-5
     assert mod.hip_trainer(vol.device).dcond is None
+
+
+def test_p_sample_loop_box_branch_vs_reference_golden(diffusion, synth):
+    """p_sample_loop(box=...) of the mirror (reference cond_DDPM.py:455-459, the x_T masking as written) on the HIP path against the
+    reference's own output"""
+    g = golden("box_loop_B3_32x32_T1000_start6")
+    B, H, W, start_t = 3, 32, 32, 6
+    cond = torch.from_numpy(synth.synth_cond(1, 0, B)).cuda()
+    xT = torch.from_numpy(synth.noise_xT(2, 0, B, H, W)).cuda()
+    z = torch.zeros((start_t, B, 1, H, W), dtype=torch.float32)
+    for t in range(1, start_t):
+        z[t] = torch.from_numpy(synth.noise_z(3, t, 0, B, H, W))
+    out = diffusion.p_sample_loop((B, 1, H, W), cond=cond, start_t=start_t, box=torch.from_numpy(g["box"]), x_T=xT, z_noise=z.cuda())
+    err = float(np.abs(out.cpu().numpy() - g["out"]).max())
+    print("box branch vs reference golden:", err)
+    assert err < TOL

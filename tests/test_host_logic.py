@@ -95,7 +95,13 @@ def test_diffusion_mirror_buffers_and_errors(oracle):
     with pytest.raises(RuntimeError):
         d.p_sample_loop((1, 1, 32, 32), cond=torch.zeros(1, 128))                # CPU tensors: loud, no fallback
     with pytest.raises(NotImplementedError):
-        d.p_sample_loop((1, 1, 32, 32), cond=torch.zeros(1, 128), box=torch.zeros(1, 4))   # box in-painting: out of scope
+        d.sample(batch_size=1, cond=torch.zeros(1, 128), box=torch.zeros(1, 4), x_start=torch.zeros(1, 1, 32, 32))   # ddim_sample_box: undefined in the reference
+    # the box lines of p_sample_loop (cond_DDPM.py:455-459) as written: sample 0 keeps x_T inside its box, the others start from zeros
+    x = torch.arange(3 * 1 * 4 * 5, dtype=torch.float32).reshape(3, 1, 4, 5) + 1
+    m = D.mask_x_T_to_box(x, torch.tensor([[1, 0, 4, 2], [0, 0, 5, 4], [2, 1, 3, 3]]))
+    want = torch.zeros_like(x)
+    want[0, :, 0:2, 1:4] = x[0, :, 0:2, 1:4]
+    assert torch.equal(m, want)
     with pytest.raises(AssertionError):
         D.GaussianDiffusion(m, image_size=32, objective="pred_v")
     with pytest.raises(ValueError):

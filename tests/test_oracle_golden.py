@@ -216,3 +216,19 @@ def test_clip_denoised_false(oracle, synth, sd_torch):
     out = oracle.ddim_sample(x, cond, sd_torch, buf, lambda t: torch.from_numpy(synth.noise_z(3, t, 0, B, H, W)), 10, 1.0, 0, None,
                              clip_denoised=False).numpy()
     assert np.abs(out - golden("noclip_ddim_B2_32x32_T1000_S10_eta1")["out"]).max() <= TOL
+
+
+def test_box_branch_of_p_sample_loop(oracle, synth, sd_torch):
+    """the reference's `box` lines (cond_DDPM.py:455-459) as written -- sample 0 keeps x_T inside its box, every other sample starts from
+    zeros (`img = img_patch` inside the loop) -- restated by cond_DDPM.mask_x_T_to_box: the oracle on that masked x_T reproduces the
+    reference's own output (oracle/make_golden_box.py)"""
+    from conftest import load_pkg
+    D = load_pkg("cond_DDPM")
+    g = golden("box_loop_B3_32x32_T1000_start6")
+    B, H, W, T, start_t = 3, 32, 32, 1000, 6
+    cond = torch.from_numpy(synth.synth_cond(1, 0, B))
+    xT = D.mask_x_T_to_box(torch.from_numpy(synth.noise_xT(2, 0, B, H, W)), g["box"])
+    assert float(xT[1:].abs().max()) == 0.0 and float(xT[0].abs().max()) > 0
+    out = oracle.p_sample_loop(xT, cond, sd_torch, oracle.schedule_buffers(T),
+                               lambda t: torch.from_numpy(synth.noise_z(3, t, 0, B, H, W)), start_t=start_t)
+    assert float(np.abs(out.numpy() - g["out"]).max()) < 2e-6
