@@ -276,21 +276,43 @@ class GaussianDiffusion(nn.Module):
 
     @torch.no_grad()
     def p_losses(self, x_start, t, cond=None, noise=None, box=None, scale_patch=1, onlybox=False, mask=None):
-        """single-step reconstruction (cond_DDPM.py:565-645), x_start in [-1,1]; returns (loss, reco in [0,1])"""
-        if box is not None or self.inpaint:
-            raise NotImplementedError("box / inpaint variants are not part of the cDDPM path")
+        """single-step reconstruction (cond_DDPM.py:565-645), x_start in [-1,1]; returns (loss, reco in [0,1]). `box` ([B,4] rows
+        (x0, y1, x2, y3)): only the box of each slice is noised -- the UNet sees x_start with q_sample's box pasted in (:592-598) -- and
+        under pred_noise the target is the noise inside the box, zero outside (:611-615); `inpaint` (constructor flag) pastes the model's
+        box back into x_start before the loss (:626-633). `scale_patch` / `onlybox` are accepted and unused, as in the reference."""
+        if self.inpaint and box is None:
+            raise ValueError("inpaint=True needs a box (the reference indexes box[i] unconditionally, cond_DDPM.py:632)")
         if noise is None:
             noise = torch.randn_like(x_start)
         B, _c, H, W = x_start.shape
         eng = self._engine(B, H, W, x_start.device)
         x = eng.q_sample((x_start.float() + 1) * 0.5, t, noise.float())
+        boxes = None
+        if box is not None:
+            boxes = [tuple(int(v) for v in box[i]) for i in range(B)]
+            xb = x_start.float().clone()
+            for i, (x0, y1, x2, y3) in enumerate(boxes):
+                xb[i, :, y1:y3, x0:x2] = x[i, :, y1:y3, x0:x2]
+            x = xb.contiguous()
         out = eng.unet_forward(x, t, cond.float() if cond is not None else None)
         if self.objective == "pred_noise":
-            target = noise
+            if boxes is not None:
+                target = torch.zeros_like(noise)
+                for i, (x0, y1, x2, y3) in enumerate(boxes):
+                    target[i, :, y1:y3, x0:x2] = noise[i, :, y1:y3, x0:x2]
+            else:
+                target = noise
         else:
             if mask is not None:
                 out = out * mask
             target = x_start
+        if self.inpaint:
+            pasted = x_start.float().clone()
+            if pasted.shape[1] == 2:
+                pasted = pasted[:, 0].unsqueeze(1)
+            for i, (x0, y1, x2, y3) in enumerate(boxes):
+                pasted[i, :, y1:y3, x0:x2] = out[i, :, y1:y3, x0:x2]
+            out = pasted
         loss = self.loss_fn(out, target, reduction="none").reshape(B, -1).mean(dim=1)
         loss = loss * self.p2_loss_weight.gather(-1, t.long())
         if self.objective == "pred_noise":

@@ -54,5 +54,37 @@ def main():
     print(NAME, "oracle (on the masked x_T) vs reference:", err)
 
 
+def p_losses_cases():
+    """GaussianDiffusion.forward -> p_losses with a box (cond_DDPM.py:592-598, :611-615) and with inpaint=True (:626-633), both
+    objectives: the reference's (loss, reco) on seeded inputs"""
+    B, H, W, T, t = 3, 32, 32, 1000, 350
+    sd = O.to_torch_sd(synth.synth_state_dict(0))
+    x01 = torch.from_numpy(synth.synth_slices(2, 0, B, H, W))
+    cond = torch.from_numpy(synth.synth_cond(1, 0, B))
+    noise = torch.from_numpy(synth.noise_z(3, 0, 0, B, H, W))
+    box = torch.tensor(BOX, dtype=torch.long)
+    out = {}
+    for objective, loss_type, inpaint in (("pred_noise", "l2", False), ("pred_x0", "l1", False), ("pred_x0", "l1", True), ("pred_noise", "l2", True)):
+        _m, diff = R.build_reference(sd, image_size=(H, W), timesteps=T, objective=objective)
+        _u, GaussianDiffusion = R.import_reference()
+        diff = GaussianDiffusion(_m, image_size=(H, W), timesteps=T, sampling_timesteps=T, objective=objective, channels=1,
+                                 loss_type=loss_type, p2_loss_weight_gamma=0, inpaint=inpaint, cfg=None)
+        diff.use_spatial_transformer = False
+        diff.eval()
+        with torch.no_grad():
+            loss, reco = diff(x01, t=t, cond=cond, noise=noise, box=box)
+        key = f"{objective}_{loss_type}_{'inpaint' if inpaint else 'box'}"
+        out[key + "_loss"], out[key + "_reco"] = loss.numpy(), reco.numpy()
+        print(key, float(loss))
+    name = "box_p_losses_B3_32x32_t350"
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), box=np.array(BOX, np.int64), **out)
+    mpath = os.path.join(GOLD, "MANIFEST.json")
+    man = json.load(open(mpath))
+    man["cases"][name] = dict(B=B, H=H, W=W, timesteps=T, t=t, box=BOX, variants=sorted(k[:-5] for k in out if k.endswith("_loss")),
+                              seeds=dict(weights=0, cond=1, x01=2, noise=3), note="reference outputs (loss, reco) of forward -> p_losses")
+    json.dump(man, open(mpath, "w"), indent=1, sort_keys=True)
+
+
 if __name__ == "__main__":
     main()
+    p_losses_cases()

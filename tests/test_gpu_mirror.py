@@ -393,3 +393,32 @@ def test_p_sample_loop_box_branch_vs_reference_golden(diffusion, synth):
     err = float(np.abs(out.cpu().numpy() - g["out"]).max())
     print("box branch vs reference golden:", err)
     assert err < TOL
+
+
+@pytest.mark.parametrize("objective,loss_type,inpaint", [("pred_noise", "l2", False), ("pred_x0", "l1", False), ("pred_x0", "l1", True),
+                                                         ("pred_noise", "l2", True)])
+def test_p_losses_box_and_inpaint_variants_vs_reference_golden(sd_np, synth, objective, loss_type, inpaint):
+    """GaussianDiffusion.forward -> p_losses with `box` (only the box is noised; pred_noise: the target is the noise inside the box) and
+    with inpaint=True (the model's box pasted back into x_start before the loss): reference cond_DDPM.py:592-598, :611-615, :626-633;
+    (loss, reco) against the reference's own outputs (oracle/make_golden_box.py)"""
+    U, D = load_pkg("OpenAI_Unet"), load_pkg("cond_DDPM")
+    g = golden("box_p_losses_B3_32x32_t350")
+    m = U.UNetModel(image_size=(32, 32), in_channels=1, model_channels=128, out_channels=1, num_res_blocks=3,
+                    attention_resolutions=(3, 6, 12), dropout=0, channel_mult=[1, 2, 2], conv_resample=True, dims=2,
+                    num_classes=128, use_checkpoint=False, use_fp16=True, num_heads=1, num_head_channels=64,
+                    num_heads_upsample=-1, use_scale_shift_norm=True, resblock_updown=True, use_new_attention_order=True,
+                    use_spatial_transformer=False, transformer_depth=1)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()}, strict=True)
+    d = D.GaussianDiffusion(m, image_size=(32, 32), timesteps=1000, sampling_timesteps=1000, objective=objective, channels=1,
+                            loss_type=loss_type, p2_loss_weight_gamma=0, inpaint=inpaint, cfg=None).cuda()
+    B, H, W = 3, 32, 32
+    x01 = torch.from_numpy(synth.synth_slices(2, 0, B, H, W)).cuda()
+    cond = torch.from_numpy(synth.synth_cond(1, 0, B)).cuda()
+    noise = torch.from_numpy(synth.noise_z(3, 0, 0, B, H, W)).cuda()
+    loss, reco = d(x01, t=350, cond=cond, noise=noise, box=torch.from_numpy(g["box"]))
+    key = f"{objective}_{loss_type}_{'inpaint' if inpaint else 'box'}"
+    e_reco = float(np.abs(reco.cpu().numpy() - g[key + "_reco"]).max())
+    e_loss = abs(float(loss) - float(g[key + "_loss"]))
+    print(key, "reco", e_reco, "loss", e_loss)
+    assert e_reco < TOL and e_loss < 1e-5
+    m._hip.close()
