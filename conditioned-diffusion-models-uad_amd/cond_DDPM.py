@@ -265,6 +265,22 @@ class GaussianDiffusion(nn.Module):
                                   box=box, start_t=start_t, noise=noise, x_start=x_start, **kw)
 
     @torch.no_grad()
+    def interpolate(self, x1, x2, t=None, lam=0.5, *, cond=None, seed=None):
+        """(cond_DDPM.py:532-546) both images noised to step t, mixed (1 - lam) : lam, then t reverse steps; returns the chain's last state
+        in [-1, 1] like the reference (no unnormalise). The reference's own loop cannot run -- it hands p_sample a tensor for `t` (:544,
+        SURVEY 8a "latent bugs") and no context -- so this follows the intended semantics; `cond` (absent in the reference's signature)
+        is the context the conditioned UNet needs."""
+        assert x1.shape == x2.shape
+        b = x1.shape[0]
+        t = self.num_timesteps - 1 if t is None else int(t)
+        tb = torch.full((b,), t, device=x1.device, dtype=torch.long)
+        img = ((1 - lam) * self.q_sample(x1, tb) + lam * self.q_sample(x2, tb)).contiguous()
+        seed = self._draw_seed(seed)
+        for i in reversed(range(0, t)):
+            img = self.p_sample(img, i, cond=cond, seed=seed)
+        return img
+
+    @torch.no_grad()
     def q_sample(self, x_start, t, noise=None):
         """sqrt(abar_t) x0 + sqrt(1 - abar_t) eps on x0 in [-1,1] (cond_DDPM.py:548-554)."""
         if noise is None:

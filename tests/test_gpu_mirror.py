@@ -422,3 +422,27 @@ def test_p_losses_box_and_inpaint_variants_vs_reference_golden(sd_np, synth, obj
     print(key, "reco", e_reco, "loss", e_loss)
     assert e_reco < TOL and e_loss < 1e-5
     m._hip.close()
+
+
+def test_interpolate_mirror(diffusion, synth):
+    """GaussianDiffusion.interpolate (reference cond_DDPM.py:532-546, intended semantics): q_sample both images at t, mix, t reverse steps
+    -- the composition of the mirror's own (golden-checked) q_sample and p_sample, and lam = 0 / 1 reduce to the single-image chains"""
+    B, H, W, t = 2, 32, 32, 5
+    x1 = torch.from_numpy(synth.synth_slices(2, 0, B, H, W)).cuda() * 2 - 1
+    x2 = torch.from_numpy(synth.synth_slices(2, 7, B, H, W)).cuda() * 2 - 1
+    cond = torch.from_numpy(synth.synth_cond(1, 0, B)).cuda()
+    tb = torch.full((B,), t, device="cuda", dtype=torch.long)
+    torch.manual_seed(0)
+    got = diffusion.interpolate(x1, x2, t=t, lam=0.25, cond=cond, seed=7)
+    torch.manual_seed(0)
+    img = (0.75 * diffusion.q_sample(x1, tb) + 0.25 * diffusion.q_sample(x2, tb)).contiguous()
+    for i in reversed(range(t)):
+        img = diffusion.p_sample(img, i, cond=cond, seed=7)
+    assert got.shape == x1.shape and torch.equal(got, img) and bool(torch.isfinite(got).all())
+    torch.manual_seed(0)
+    a = diffusion.interpolate(x1, x2, t=t, lam=0.0, cond=cond, seed=7)
+    torch.manual_seed(0)
+    b = diffusion.q_sample(x1, tb)
+    for i in reversed(range(t)):
+        b = diffusion.p_sample(b, i, cond=cond, seed=7)
+    assert torch.equal(a, b)
