@@ -605,8 +605,11 @@ class UNetTrainer:
         st = self.state
         if "m" not in st:
             st["m"], st["v"] = torch.zeros_like(self.flat), torch.zeros_like(self.flat)
+        # wexp / calls: the convolutions' pre-scale exponents are refreshed every `exp_refresh` updates, not every update -- a resumed run
+        # must multiply with the exponents (and refresh on the schedule) the uninterrupted run would
         return {"m": st["m"].detach().clone(), "v": st["v"].detach().clone(), "ctrl": self._ctrl().detach().clone(),
-                "layout": [(k, int(v.numel())) for k, v in self.p.items()]}
+                "layout": [(k, int(v.numel())) for k, v in self.p.items()], "wexp": dict(getattr(self, "wexp", {})),
+                "calls": int(st.get("calls", 0))}
 
     def load_optimizer_state(self, state) -> None:
         layout = [(k, int(v.numel())) for k, v in self.p.items()]
@@ -615,6 +618,10 @@ class UNetTrainer:
         self.state["m"] = state["m"].to(self.dev, torch.float32).clone()
         self.state["v"] = state["v"].to(self.dev, torch.float32).clone()
         self._ctrl().copy_(state["ctrl"].to(self.dev, torch.int32))
+        self.state["calls"] = int(state.get("calls", 0))
+        if state.get("wexp") and self._convs:
+            self.wexp = {k: int(state["wexp"][k]) for k in self._convs}
+            self.repack()
 
     def parameters_changed(self) -> None:
         """the flat parameter buffer was written from outside (load_state_dict into the aliased module parameters): refresh the
