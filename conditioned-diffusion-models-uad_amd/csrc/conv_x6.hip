@@ -862,7 +862,7 @@ static void launch_split(const ConvArgs& a, hipStream_t stream) {
     // a.nb2 (set by the caller's plan: conv_nb2_ok): 256 couts per workgroup, the chunk's patch produced once for both cout blocks
     static const int m16_env = [] { const char* e = getenv("CDDPM_M16"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
     const bool m16 = (NS == 2) && (m16_env != 0);
-    const bool nb2 = (NS == 2) && m16 && a.nb2 && !a.hi_only && a.ksplit <= 1 && (a.Cout % 256) == 0 && a.taps != 1;
+    const bool nb2 = (NS == 2) && m16 && a.nb2 && a.ksplit <= 1 && (a.Cout % 256) == 0 && a.taps != 1;
     const unsigned grid = (unsigned)(a.B * (up2 ? 4 : 1) * tilesX * tilesY * (a.Cout / (nb2 ? 256 : 128)) * (a.ksplit > 1 ? a.ksplit : 1));
     const size_t coef_lds = a.coef ? (size_t)3 * (a.C0 + a.C1) * sizeof(float) : 0;
     auto need = [&](int npix) {
@@ -887,13 +887,18 @@ static void launch_split(const ConvArgs& a, hipStream_t stream) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_split_kernel<4, ROWS, NS, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_split_kernel<9, ROWS, NS, true, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_split_kernel<4, ROWS, NS, true, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_split_kernel<9, ROWS, NS, true, true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_split_kernel<4, ROWS, NS, true, true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         }
         attr = true;
     }
     const dim3 g(grid), blk(64 * ROWS);
     if constexpr (NS == 2) {
         if (nb2) {
-            if (a.taps == 9) hipLaunchKernelGGL((conv_split_kernel<9, ROWS, NS, true, false, 2>), g, blk, need((ROWS + 2) * 34), stream, a);
+            if (a.hi_only) {       // plain fp16 operands (the training operators under precision 16)
+                if (a.taps == 9) hipLaunchKernelGGL((conv_split_kernel<9, ROWS, NS, true, true, 2>), g, blk, need((ROWS + 2) * 34), stream, a);
+                else hipLaunchKernelGGL((conv_split_kernel<4, ROWS, NS, true, true, 2>), g, blk, need((ROWS + 1) * 33), stream, a);
+            } else if (a.taps == 9) hipLaunchKernelGGL((conv_split_kernel<9, ROWS, NS, true, false, 2>), g, blk, need((ROWS + 2) * 34), stream, a);
             else hipLaunchKernelGGL((conv_split_kernel<4, ROWS, NS, true, false, 2>), g, blk, need((ROWS + 1) * 33), stream, a);
             return;
         }
@@ -926,7 +931,8 @@ int conv_nb2_env() {
 bool conv_nb2_ok(int Cout, long long workgroups128, int ksplit, int hi_only) {
     static const bool m16 = [] { const char* e = getenv("CDDPM_M16"); return !(e && e[0] == '0'); }();
     const int on = conv_nb2_env();
-    return on && m16 && conv_mode() == 2 && ksplit <= 1 && !hi_only && (Cout % 256) == 0 && (on == 2 || workgroups128 >= 512);
+    (void)hi_only;       // both operand forms have the 256-cout instantiation
+    return on && m16 && conv_mode() == 2 && ksplit <= 1 && (Cout % 256) == 0 && (on == 2 || workgroups128 >= 512);
 }
 
 void launch_conv_split(const ConvArgs& a, hipStream_t stream) {
