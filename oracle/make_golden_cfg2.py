@@ -115,6 +115,8 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--stage", default="all", choices=("ref", "oracle", "fp64", "all"))
     ap.add_argument("--small", action="store_true", help="32x32 instead of 128x128")
+    ap.add_argument("--geometry", default="", help="BxHxW of another full-length chain, e.g. 4x96x96 (the experiment's own evaluation call: "
+                    "4 centre slices of 96x96, DDPM_2D.py:193 + DDPM_cond_spark_2D.yaml:13-14) or 1x256x256 (BASELINE config 3)")
     ap.add_argument("--threads", type=int, default=0)
     ap.add_argument("--tag", default="", help="suffix of the output name (reference stage only): a second run of the "
                     "REFERENCE under another thread count, e.g. --threads 4 --tag threads4 -- what the reference "
@@ -125,6 +127,9 @@ if __name__ == "__main__":
     B, T = 2, 1000
     H = W = 32 if a.small else 128
     name = f"loop_B2_32x32_T1000_start0" if a.small else "loop_cfg2_B2_128x128_T1000_start0"
+    if a.geometry:
+        B, H, W = (int(v) for v in a.geometry.split("x"))
+        name = f"loop_full_B{B}_{H}x{W}_T1000_start0"
     if a.tag:
         assert a.stage == "ref", "--tag is for a second reference run only"
         name = name + "_" + a.tag

@@ -123,15 +123,16 @@ print("FAMILY " + json.dumps(res))
 """
 
 
-def reference_self_consistency():
+def reference_self_consistency(name=None):
     """What the REFERENCE differs from ITSELF by on this chain: its own p_sample_loop (cond_DDPM.py:446-464) run in the build container
     with 8 threads (the golden) and again with 4 (and 2) threads (`oracle/make_golden_cfg2.py --stage ref --threads N --tag threadsN`):
     torch's CPU convolutions sum in an order that depends on the thread count, nothing else differs. The only reference-held measure of
     what two correct fp32 executions of this 1000-step chain may differ by (a LOWER bound for two different implementations: the runs
     share every kernel). Largest pairwise figures over the runs present; None when no second run is committed."""
-    runs = [golden(NAME)["out"].astype(np.float64)]
+    name = name or NAME
+    runs = [golden(name)["out"].astype(np.float64)]
     for tag in ("threads4", "threads2"):
-        p = os.path.join(GOLD, f"{NAME}_{tag}.npz")
+        p = os.path.join(GOLD, f"{name}_{tag}.npz")
         if os.path.exists(p):
             runs.append(np.load(p)["out"].astype(np.float64))
     if len(runs) < 2:
@@ -142,7 +143,7 @@ def reference_self_consistency():
             d = np.abs(runs[i] - runs[j])
             out["max"], out["rms"] = max(out["max"], float(d.max())), max(out["rms"], float(np.sqrt((d ** 2).mean())))
             out["n_over"] = max(out["n_over"], int((d > TOL).sum()))
-    truth = os.path.join(GOLD, NAME + "_fp64.npz")
+    truth = os.path.join(GOLD, name + "_fp64.npz")
     if os.path.exists(truth):       # distance of each reference run from the float64 chain: the band a correct fp32 execution falls in
         t = np.load(truth)["out"]
         e = [(float(np.abs(r - t).max()), float(np.sqrt(((r - t) ** 2).mean()))) for r in runs]
@@ -264,3 +265,42 @@ def test_two_summation_orders_of_the_same_arithmetic_at_full_length(engine_facto
           f"final max|delta| {d.max():.3e} rms {np.sqrt((d ** 2).mean()):.3e}, {(d > 1e-4).sum()} of {d.size} pixels above 1e-4")
     assert d50 < 1e-4 and np.sqrt((d ** 2).mean()) < 3e-5 and d.max() < 2e-3
     small.close()
+
+
+EXPERIMENT_CHAIN = "loop_full_B4_96x96_T1000_start0"
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(GOLD, EXPERIMENT_CHAIN + ".npz")), reason="golden of the experiment-shaped chain not generated")
+def test_full_length_chain_at_the_experiments_own_call_shape(engine_factory, synth):
+    """The reference's REAL evaluation geometry at full length: 4 centre slices of 96 x 96 (DDPM_2D.py:193; DDPM_cond_spark_2D.yaml:13-14:
+    imageDim 192 / rescaleFactor 2), all T = 1000 reverse steps, on a handle created for exactly that call (max_batch 4: the SMALL-BATCH
+    plan -- split-K ranges + deterministic combine, cddpm_api.hip::plan_ksplit -- which the B = 64 headline handle never takes) against
+    the reference's own output (`oracle/make_golden_cfg2.py --geometry 4x96x96`): captured states within 1e-4, final image by
+    _accept_final_image with this chain's own reference-vs-reference figures."""
+    B, Hh, Ww = 4, 96, 96
+    g = golden(EXPERIMENT_CHAIN)
+    eng = engine_factory(timesteps=T, max_batch=B, max_h=Hh, max_w=Ww)
+    x = torch.from_numpy(synth.noise_xT(2, 0, B, Hh, Ww)).cuda()
+    cond = torch.from_numpy(synth.synth_cond(1, 0, B)).cuda()
+    noise = torch.empty((T, B, 1, Hh, Ww), dtype=torch.float32)
+    noise[0] = 0
+    for t in range(1, T):
+        noise[t] = torch.from_numpy(synth.noise_z(3, t, 0, B, Hh, Ww))
+    nz = noise.cuda()
+    img, hi = x.clone(), T
+    eng.prepare_cond(cond, B)
+    for t_cap in sorted((int(k[3:]) for k in g.files if k.startswith("x_t")), reverse=True):
+        for t in range(hi - 1, t_cap, -1):
+            img = eng.p_sample(img, t, None, z=nz[t])
+        hi = t_cap + 1
+        err = float(np.abs(img.cpu().numpy() - g[f"x_t{t_cap}"]).max())
+        print(f"{EXPERIMENT_CHAIN} x_t{t_cap}: max|delta| {err:.3e}")
+        assert err < 2 * TOL          # states live in [-1, 1]
+    out = eng.reverse(x, cond, T, noise=nz).cpu().numpy()
+    d = np.abs(out.astype(np.float64) - g["out"])
+    err, rms, n_over = float(d.max()), float(np.sqrt((d ** 2).mean())), int((d > TOL).sum())
+    self_c = reference_self_consistency(EXPERIMENT_CHAIN)
+    print(f"{EXPERIMENT_CHAIN}: HIP (small-batch plan) vs reference max|delta| {err:.3e} rms {rms:.3e}, {n_over} of {d.size} pixels above 1e-4; "
+          f"reference vs itself: {self_c}")
+    assert out.min() >= 0.0 and out.max() <= 1.0
+    _accept_final_image("h3, B=4 96x96 small-batch plan", err, rms, n_over, d.size, self_c)

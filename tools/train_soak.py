@@ -28,4 +28,5 @@ for step in range(N):
     if (step + 1) % 10 == 0:
         print(f"step {step + 1:4d}  mean loss of the last 10: {sum(acc[-10:]) / 10:.4f}", flush=True)
 assert all(l == l and abs(l) < 1e6 for l in acc), "non-finite loss"
-print("first 10:", sum(acc[:10]) / 10, "last 10:", sum(acc[-10:]) / 10, "exponents", sorted(set(trainer.wexp.values())))
+print("first 10:", sum(acc[:10]) / 10, "last 10:", sum(acc[-10:]) / 10, "exponents", sorted(set(trainer.wexp.values())),
+      "precision", tr.get_precision(), "optimizer steps", trainer.step_count, "skipped (non-finite gradients)", trainer.skipped_steps)
