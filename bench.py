@@ -179,13 +179,18 @@ def training_rate(torch, dev, synth, B=16, S=128, steps=3, precision=32):
         dt = (time.perf_counter() - t0) / steps
         losses.append(float(loss))
         # per-operator-class HIP events over one more step (outside the timed steps)
-        trainer.eng.set_profiling(True)
+        engines = [e for e in (trainer.eng, getattr(trainer, "eng_w", None)) if e is not None]     # eng_w: the weight gradients' side-stream handle
+        for e in engines:
+            e.set_profiling(True)
         tr.training_step(trainer, x01, None, **kw)
         torch.cuda.synchronize(dev)
-        trainer.eng.set_profiling(False)
-        prof = trainer.eng.get_profile()
+        prof = None
+        for e in engines:
+            e.set_profiling(False)
+            p_ = e.get_profile()
+            prof = p_ if prof is None else {k: {kk: prof[k][kk] + p_[k][kk] for kk in prof[k]} for k in prof}
         skipped = trainer.skipped_steps
-        trainer.eng.close()
+        trainer.close()
     finally:
         tr.set_precision(32)
     nprod = 3.0 if bits == 32 else 1.0                # MFMAs executed per product group: hi*hi + hi*mid + mid*hi, or hi*hi alone
@@ -198,6 +203,7 @@ def training_rate(torch, dev, synth, B=16, S=128, steps=3, precision=32):
             roof[cls] = {"bound": "mfma", "kernel": what, "achieved": nprod * ach, "peak": PEAK_16BIT_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": nprod * ach / PEAK_16BIT_MFMA_TFLOPS, "fp32_equivalent_tflops": ach, "ms_per_step": c["ms"], "launches": c["launches"],
                          "products_per_multiply": nprod}
+    # (the weight gradients run on a side stream beside the main stream's chain: the classes' times overlap, their sum exceeds the step)
     classes = {k: {"ms_per_step": v["ms"], "launches": v["launches"]} for k, v in prof.items() if v["launches"]}
     return {"workload": f"{B}x1x{S}x{S}, noise-pred MSE, Adam, UNet + context encoder", "ms_per_step": dt * 1e3, "slices_per_s": B / dt,
             "precision": bits, "dtype": ("f32_emulated_f16x3 (convolutions), f32 elsewhere" if bits == 32 else

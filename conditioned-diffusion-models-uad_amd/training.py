@@ -93,7 +93,7 @@ class UNetTrainer:
     input gradient. No operator synchronises: temporaries come from the handle's scratch arena."""
 
     def __init__(self, params: Dict[str, torch.Tensor], *, model_channels=128, channel_mult=(1, 2, 2), num_res_blocks=3,
-                 cond_dim=128, device=None, exp_refresh=50):
+                 cond_dim=128, device=None, exp_refresh=50, overlap_wgrad=None):
         self.dev = torch.device(device) if device is not None else next(iter(params.values())).device
         self._cfg = dict(model_channels=model_channels, channel_mult=tuple(channel_mult), num_res_blocks=num_res_blocks, cond_dim=cond_dim)
         self.C, self.mult, self.nres, self.cond_dim = model_channels, tuple(channel_mult), num_res_blocks, cond_dim
@@ -128,6 +128,13 @@ class UNetTrainer:
             self.emb_b, self.emb_gb = self.flat[nw:nw + self.emb_rows], self.gflat[nw:nw + self.emb_rows]
         self.state: Dict[str, object] = {}
         self.eng: Optional[CddpmEngine] = None
+        # weight gradients on a SIDE stream (and a second handle: an operator's temporaries come from its handle's arena, one call at a
+        # time): nothing in the backward pass waits for a weight gradient, so the k-image passes (memory bound) and the wgrad GEMMs run
+        # beside the dgrad / GroupNorm-backward chain of the main stream instead of between its links. CDDPM_TRAIN_OVERLAP=0 switches off.
+        import os as _os
+        self.overlap_wgrad = (_os.environ.get("CDDPM_TRAIN_OVERLAP", "1") != "0") if overlap_wgrad is None else bool(overlap_wgrad)
+        self.eng_w: Optional[CddpmEngine] = None
+        self.side = None
         self.grad_scale = 1.0
         self.exp_refresh = exp_refresh
         self._convs = self._conv_table()
@@ -166,6 +173,15 @@ class UNetTrainer:
             rc = self.eng.lib.cddpm_op_set_scratch(self.eng._h, arena)
             if rc != 0:
                 raise RuntimeError("cddpm_op_set_scratch failed: " + self.eng.lib.cddpm_last_error(self.eng._h).decode())
+            if self.overlap_wgrad:
+                if self.eng_w is not None:
+                    self.eng_w.close()
+                # the weight-gradient handle: only its operator arena is used (k-images + partial tiles); smallest geometry
+                self.eng_w = CddpmEngine(timesteps=2, max_batch=1, max_h=16, max_w=16, device=self.dev, **self._cfg)
+                if self.eng_w.lib.cddpm_op_set_scratch(self.eng_w._h, 2 * ((B + 7) // 8) * worst * 16 + (192 << 20)) != 0:
+                    raise RuntimeError("cddpm_op_set_scratch failed: " + self.eng_w.lib.cddpm_last_error(self.eng_w._h).decode())
+                if self.side is None:
+                    self.side = torch.cuda.Stream(device=self.dev)
         self.lib, self.h = self.eng.lib, self.eng._h
 
     def refresh_exponents(self):
@@ -322,9 +338,36 @@ class UNetTrainer:
         """dL/dW (and dL/db) of convolution `name` into the gradient buffer"""
         co, ci, ks, _folded, _g = self._convs[name]
         B, H, W, _c = dy.shape
+        if self.overlap_wgrad and self.side is not None:
+            main = torch.cuda.current_stream(self.dev)
+            self.side.wait_stream(main)                       # the operands are products of the main stream's work so far
+            rc = self.lib.cddpm_op_conv_wgrad(self.eng_w._h, _p(x0), x0.shape[-1], _p(x1), x1.shape[-1] if x1 is not None else 0, _p(coef),
+                                              int(bool(silu)), int(bool(upsample)), _p(dy), co, ks, _p(self.g[name + ".weight"]),
+                                              _p(self.g[name + ".bias"]) if bias else None, B, H, W, self.side.cuda_stream)
+            if rc != 0:
+                raise RuntimeError("op_conv_wgrad failed: " + self.lib.cddpm_last_error(self.eng_w._h).decode())
+            for t_ in (x0, x1, coef, dy):                      # their memory must outlive the side stream's reads
+                if t_ is not None:
+                    t_.record_stream(self.side)
+            self._side_busy = True
+            return
         self._ck(self.lib.cddpm_op_conv_wgrad(self.h, _p(x0), x0.shape[-1], _p(x1), x1.shape[-1] if x1 is not None else 0, _p(coef), int(bool(silu)),
                                               int(bool(upsample)), _p(dy), co, ks, _p(self.g[name + ".weight"]),
                                               _p(self.g[name + ".bias"]) if bias else None, B, H, W, self._s()), "op_conv_wgrad")
+
+    def close(self):
+        """releases the handles (operator arenas, workspaces)"""
+        for e in (self.eng, self.eng_w):
+            if e is not None:
+                e.close()
+        self.eng = self.eng_w = None
+
+    def join_side(self):
+        """the main stream waits for the weight gradients issued on the side stream so far (before the gradient buffer is read: an
+        all-reduce bucket, the guard, Adam)"""
+        if getattr(self, "_side_busy", False):
+            torch.cuda.current_stream(self.dev).wait_stream(self.side)
+            self._side_busy = False
 
     def unpool2(self, dyp, scale, into=None):
         B, h, w, Cc = dyp.shape
@@ -469,14 +512,14 @@ class UNetTrainer:
                 d, _ = self.gn_bwd(r["x"], dact, "out.0", rec=r["rec"])
             elif kind == "attn":
                 r = sv[name]
-                da = self.dgrad(name + ".proj_out", d)
                 self.wgrad(name + ".proj_out", r["att"], None, None, False, d)
+                da = self.dgrad(name + ".proj_out", d)
                 Bc, h_, w_, Cc = r["x"].shape
                 dqkv = torch.empty_like(r["qkv"])
                 self._ck(self.lib.cddpm_op_attention_backward(self.h, _p(r["qkv"]), _p(da), _p(dqkv), Bc, h_ * w_, Cc, self._s()),
                          "op_attention_backward")
-                dn = self.dgrad(name + ".qkv", dqkv)
                 self.wgrad(name + ".qkv", r["x"], None, r["coefn"], False, dqkv)
+                dn = self.dgrad(name + ".qkv", dqkv)
                 d, _ = self.gn_bwd(r["x"], dn, name + ".norm", None, False, rec=r["rec"], add=d)       # + the residual path x + h
             elif kind == "res":
                 if a.get("push"):        # this op's output also fed a skip connection: add that gradient
@@ -485,32 +528,33 @@ class UNetTrainer:
                 x0, x1, h1, film = r["x0"], r["x1"], r["h1"], r["film"]
                 c1, c2 = name + ".in_layers.2", name + ".out_layers.3"
                 # out = conv2(act2(h1)) + skip(x)
+                self.wgrad(c2, h1, None, r["coef2"], True, d)             # (weight gradients first: they start on the side stream while
+                if a["cin"] != a["cout"]:                                  #  the main stream runs the input gradients)
+                    self.wgrad(name + ".skip_connection", x0, x1, None, False, d)
                 da2 = self.dgrad(c2, d)
-                self.wgrad(c2, h1, None, r["coef2"], True, d)
                 dxs = None
                 if a["cin"] != a["cout"]:
                     dxs = self.dgrad(name + ".skip_connection", d)            # [B,H,W,Cin] over the concatenation
-                    self.wgrad(name + ".skip_connection", x0, x1, None, False, d)
                 dh1, dfilm = self.gn_bwd(h1, da2, name + ".out_layers.0", film, rec=r["rec_h1"])
                 if dfilm_all is not None:
                     dfilm_all[:, self.emb_off[name]:self.emb_off[name] + dfilm.shape[1]].copy_(dfilm)     # one backward for all blocks below
                 else:
                     self.add_(demb, self.linear_bwd(sv["emb"], name + ".emb_layers.1", dfilm, True))       # film = Linear(SiLU(emb))
                 if a["kind"] == "down":
-                    dhp = self.dgrad(c1, dh1)
                     self.wgrad(c1, r["hp"], None, None, False, dh1)
+                    dhp = self.dgrad(c1, dh1)
                     da1 = self.unpool2(dhp, 0.25)
                     dx, _ = self.gn_bwd(x0, da1, name + ".in_layers.0", rec=r["rec_in"])
                     self.unpool2(d, 0.25, into=dx)                            # identity skip through avg_pool(x)
                 elif a["kind"] == "up":
-                    dau = self.dgrad(c1, dh1)                                 # gradient of the upsampled activation
                     self.wgrad(c1, x0, None, r["coef1"], True, dh1, upsample=True)
+                    dau = self.dgrad(c1, dh1)                                 # gradient of the upsampled activation
                     da1 = self.sumpool2(dau)
                     dx, _ = self.gn_bwd(x0, da1, name + ".in_layers.0", rec=r["rec_in"])
                     self.sumpool2(d, into=dx)                                 # identity skip through the upsampled x
                 else:
-                    da1 = self.dgrad(c1, dh1)
                     self.wgrad(c1, x0, x1, r["coef1"], True, dh1)
+                    da1 = self.dgrad(c1, dh1)
                     dx, _ = self.gn_bwd(x0, da1, name + ".in_layers.0", rec=r["rec_in"], x1=x1,
                                         add=dxs if dxs is not None else d)        # + the 1x1 skip_connection's gradient, or the identity skip's
                 if x1 is not None:       # the gradient of the concatenation arrives split: [h | popped skip tensor]
@@ -524,6 +568,8 @@ class UNetTrainer:
                          "op_chan_image_corr")
                 self._ck(self.lib.cddpm_op_bias_grad(self.h, _p(d), B * H * W, self.C, _p(g[name + ".bias"]), self._s()), "op_bias_grad")
             if buckets is not None:      # this operator's tensors are final (its emb_layers too unless they are batched at the buffer's head)
+                if getattr(buckets, "on", True):
+                    self.join_side()     # ... once the side stream's weight gradients have landed (a collective reads the buffer)
                 buckets.mark_final(self.grad_offset(name + "."))
         assert not skip_grads
         if dfilm_all is not None:       # film_all = Linear(SiLU(emb)): dW / db of all 27 emb_layers (contiguous in the gradient buffer) and demb
@@ -540,6 +586,7 @@ class UNetTrainer:
             det, self.dcond = demb, None
         dy1 = self.linear_bwd(sv["y1"], "time_embed.2", det, True)
         self.linear_bwd(sv["temb"], "time_embed.0", dy1, False)
+        self.join_side()         # every gradient of the buffer is in place for whoever reads it next
         self.saved = None
         return g
 
