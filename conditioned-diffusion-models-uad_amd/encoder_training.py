@@ -116,6 +116,18 @@ class EncoderTrainer:
     def wgrad(self, name, x, dz):
         co, ci, kk, st = self.convs[name]
         B, H, W, _c = x.shape
+        ops = self.ops
+        if getattr(ops, "overlap_wgrad", False) and getattr(ops, "side", None) is not None:
+            # as the UNet's weight gradients (training.UNetTrainer.wgrad): on the side stream and its handle, beside the main stream's chain
+            # of small BatchNorm / input-gradient kernels
+            ops.side.wait_stream(torch.cuda.current_stream(self.dev))
+            rc = self.lib.cddpm_op_enc_conv_wgrad(ops.eng_w._h, _p(x), _p(dz), _p(self.g[name + ".weight"]), B, H, W, ci, co, kk, st, ops.side.cuda_stream)
+            if rc != 0:
+                raise RuntimeError("op_enc_conv_wgrad failed: " + self.lib.cddpm_last_error(ops.eng_w._h).decode())
+            x.record_stream(ops.side)
+            dz.record_stream(ops.side)
+            ops._side_busy = True
+            return
         self._ck(self.lib.cddpm_op_enc_conv_wgrad(self.h, _p(x), _p(dz), _p(self.g[name + ".weight"]), B, H, W, ci, co, kk, st, self._s()),
                  "op_enc_conv_wgrad")
 
@@ -224,6 +236,8 @@ class EncoderTrainer:
                 self.ops.add_(dinp, dsc)
             d = dinp
             if buckets is not None:
+                if getattr(buckets, "on", True) and hasattr(self.ops, "join_side"):
+                    self.ops.join_side()          # the side stream's weight gradients have landed before a collective reads the buffer
                 buckets.mark_final(self.grad_offset(n + "."))
         a0, z0 = sv["a0"], sv["z0"]
         B, H1, W1, _c = a0.shape
@@ -233,6 +247,8 @@ class EncoderTrainer:
         x = sv["x"]
         self._ck(self.lib.cddpm_op_enc_stem_wgrad(self.h, _p(x), _p(dz0), _p(g["conv1.weight"]), B, x.shape[2], x.shape[3], self._s()),
                  "op_enc_stem_wgrad")
+        if hasattr(self.ops, "join_side"):
+            self.ops.join_side()
         self.saved = None
         return g
 
