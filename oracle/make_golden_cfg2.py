@@ -34,22 +34,38 @@ SEED_W, SEED_COND, SEED_XT, SEED_Z = 0, 1, 2, 3
 CAPTURE_T = (750, 500, 250, 50)          # x_t as the reference holds it when it ENTERS step t
 
 
-def inputs(B, H, W):
-    cond = torch.from_numpy(synth.synth_cond(SEED_COND, 0, B))
-    xT = torch.from_numpy(synth.noise_xT(SEED_XT, 0, B, H, W))
+def inputs(B, H, W, slice0=0):
+    cond = torch.from_numpy(synth.synth_cond(SEED_COND, slice0, B))
+    xT = torch.from_numpy(synth.noise_xT(SEED_XT, slice0, B, H, W))
     return cond, xT
 
 
-def z_of(B, H, W):
-    return lambda t: torch.from_numpy(synth.noise_z(SEED_Z, t, 0, B, H, W))
+def z_of(B, H, W, slice0=0):
+    return lambda t: torch.from_numpy(synth.noise_z(SEED_Z, t, slice0, B, H, W))
 
 
-def run_reference(name, B, H, W, T):
+def run_reference_per_slice(name, B, H, W, T):
+    """the same chain with every slice run ALONE (B = 1, its own global slice index: identical inputs and noise): what the reference's
+    result for a slice owes to the batch it was evaluated in (torch's CPU convolutions partition their work over the batch first)"""
+    outs, caps, secs = [], {}, 0.0
+    for i in range(B):
+        secs += run_reference(name + f"__slice{i}", 1, H, W, T, slice0=i)
+        g = np.load(os.path.join(GOLD, name + f"__slice{i}.npz"))
+        outs.append(g["out"])
+        for k in g.files:
+            if k.startswith("x_t"):
+                caps.setdefault(k, []).append(g[k])
+        os.remove(os.path.join(GOLD, name + f"__slice{i}.npz"))
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), out=np.concatenate(outs, 0), **{k: np.concatenate(v, 0) for k, v in caps.items()})
+    return secs
+
+
+def run_reference(name, B, H, W, T, slice0=0):
     import ref_harness as R
     sd = O.to_torch_sd(synth.synth_state_dict(SEED_W))
     _m, diff = R.build_reference(sd, image_size=(H, W), timesteps=T)
-    cond, xT = inputs(B, H, W)
-    z = z_of(B, H, W)
+    cond, xT = inputs(B, H, W, slice0)
+    z = z_of(B, H, W, slice0)
     captured = {}
     state = {"t": T - 1, "t0": time.time()}
     orig_randn, orig_like = torch.randn, torch.randn_like
@@ -118,6 +134,7 @@ if __name__ == "__main__":
     ap.add_argument("--geometry", default="", help="BxHxW of another full-length chain, e.g. 4x96x96 (the experiment's own evaluation call: "
                     "4 centre slices of 96x96, DDPM_2D.py:193 + DDPM_cond_spark_2D.yaml:13-14) or 1x256x256 (BASELINE config 3)")
     ap.add_argument("--threads", type=int, default=0)
+    ap.add_argument("--per-slice", action="store_true", help="with --tag: run every slice alone (B = 1) and concatenate")
     ap.add_argument("--tag", default="", help="suffix of the output name (reference stage only): a second run of the "
                     "REFERENCE under another thread count, e.g. --threads 4 --tag threads4 -- what the reference "
                     "differs from ITSELF by at full length")
@@ -136,7 +153,7 @@ if __name__ == "__main__":
     base = dict(B=B, H=H, W=W, timesteps=T, start_t=0, captured_t=list(CAPTURE_T),
                 seeds=dict(weights=SEED_W, cond=SEED_COND, xT=SEED_XT, z=SEED_Z))
     if a.stage in ("ref", "all"):
-        s = run_reference(name, B, H, W, T)
+        s = run_reference_per_slice(name, B, H, W, T) if a.per_slice else run_reference(name, B, H, W, T)
         manifest_update(name, **base, reference_seconds=round(s, 1), threads=torch.get_num_threads())
         print(name, f"reference done {s:.0f}s", flush=True)
     if a.stage in ("oracle", "all"):

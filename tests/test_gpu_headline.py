@@ -125,13 +125,14 @@ print("FAMILY " + json.dumps(res))
 
 def reference_self_consistency(name=None):
     """What the REFERENCE differs from ITSELF by on this chain: its own p_sample_loop (cond_DDPM.py:446-464) run in the build container
-    with 8 threads (the golden) and again with 4 (and 2) threads (`oracle/make_golden_cfg2.py --stage ref --threads N --tag threadsN`):
-    torch's CPU convolutions sum in an order that depends on the thread count, nothing else differs. The only reference-held measure of
+    with 8 threads (the golden) and again with 4 (and 2) threads (`oracle/make_golden_cfg2.py --stage ref --threads N --tag threadsN`)
+    or with every slice evaluated alone (`--per-slice --tag perslice`: at B = 4 the thread count alone changes nothing, torch partitions
+    over the batch): torch's CPU convolutions sum in an order that depends on how their work is partitioned, nothing else differs. The only reference-held measure of
     what two correct fp32 executions of this 1000-step chain may differ by (a LOWER bound for two different implementations: the runs
     share every kernel). Largest pairwise figures over the runs present; None when no second run is committed."""
     name = name or NAME
     runs = [golden(name)["out"].astype(np.float64)]
-    for tag in ("threads4", "threads2"):
+    for tag in ("threads4", "threads2", "perslice"):      # perslice: every slice run alone (B = 1) -- what a slice owes to its batch
         p = os.path.join(GOLD, f"{name}_{tag}.npz")
         if os.path.exists(p):
             runs.append(np.load(p)["out"].astype(np.float64))
