@@ -34,7 +34,8 @@ Extra objects on the JSON line:
                 median); the fastest point is re-sampled (5 timed steps): value = median, `range` = slowest .. fastest step.
   config.alt_paths   the same workload (10 reverse steps, B = 64) under CDDPM_CONV=f32 (strict fp32 MFMA,
                 v_mfma_f32_32x32x2_f32 -- the arithmetic `north_star` names) and CDDPM_CONV=x6 (exact 3-term bf16 split),
-                each in a child process (the family is chosen once per process).
+                each in a child process (the family is chosen once per process); `h3_nb2`: the default family with the opt-in
+                256-cout-workgroup plan on every step (cddpm_set_accumulation_switch(0): faster, two-level accumulation).
   config.small_batch the reference's real call shape (DDPM_2D.py:193: 4 slices per volume): B = 4, 50 reverse steps.
   config.training_step  BASELINE config 5's per-GPU share (16 x 1 x 128 x 128, noise-prediction MSE, Adam; the context encoder trained jointly,
                 as the reference does): ms per optimisation step on the HIP operators (training.py), 1 warm-up + 3 timed steps.
