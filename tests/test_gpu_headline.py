@@ -6,7 +6,7 @@ Chain of evidence (each link asserted below):
      (tests/golden/loop_cfg2_B2_128x128_T1000_start0.npz, oracle/make_golden_cfg2.py): the intermediate states x_750, x_500,
      x_250, x_50 the reference held along the way within 1e-4 (observed <= 1.2e-5); the final image within 1e-4 OR, where it
      is not (observed: max 1.5e-4, 8 of 32768 pixels above 1e-4), within twice what the REFERENCE differs from ITSELF by when
-     it is run again with another thread count (committed fixtures *_threads4 / *_threads2: max 1.0e-4, rms 5.6e-6) -- see
+     it is run again with another thread count (committed fixture *_threads4: max 1.0e-4, rms 5.6e-6; 2 threads == 4 threads bit for bit) -- see
      _accept_final_image. The same chain under CDDPM_CONV=f32 (exact fp32 products) lands at max 1.6e-4: the excess over 1e-4
      is the chain's amplification of ANY fp32-level difference, not the fp16 split's (test_full_length_chain_in_all_three_...).
   2. HIP(B=2, device Philox)  ==  HIP(B=2, explicit z = the Philox draws downloaded)               bit for bit
