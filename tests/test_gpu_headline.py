@@ -132,7 +132,8 @@ def reference_self_consistency(name=None):
     share every kernel). Largest pairwise figures over the runs present; None when no second run is committed."""
     name = name or NAME
     runs = [golden(name)["out"].astype(np.float64)]
-    for tag in ("threads4", "threads2", "perslice"):      # perslice: every slice run alone (B = 1) -- what a slice owes to its batch
+    # perslice: every slice run alone (B = 1); inbatch2: a B = 1 chain's slice evaluated inside a batch of 2 -- what a slice owes to its batch
+    for tag in ("threads4", "threads2", "perslice", "inbatch2"):
         p = os.path.join(GOLD, f"{name}_{tag}.npz")
         if os.path.exists(p):
             runs.append(np.load(p)["out"].astype(np.float64))
