@@ -276,7 +276,7 @@ __global__ __launch_bounds__(64 * ROWS) void conv_split_kernel(const ConvArgs a)
             if (q < NPIX) {
                 // 4 channels = half a slot: slot u = c4 >> 1 of each split, half c4 & 1
 #pragma unroll
-                for (int sp = 0; sp < NS; ++sp) {
+                for (int sp = 0; sp < (HI1 ? 1 : NS); ++sp) {        // (hi-only products never read the mid plane: it is neither computed nor stored)
                     const int sl = M16S ? (q * 8 + ((4 * sp + (c4 >> 1)) ^ (int)((colswz >> (3 * k)) & 7u))) : slot_a(q, sp, c4 >> 1);
                     dst[sl * 2 + (c4 & 1)] = __builtin_bit_cast(v2f, sreg[k][sp]);
                 }
