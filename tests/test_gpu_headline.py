@@ -265,7 +265,10 @@ def test_two_summation_orders_of_the_same_arithmetic_at_full_length(engine_facto
     d = np.abs(a - b)
     print(f"split-K plan vs unsplit plan, B=2 x 128x128 x T=1000: state entering step 49 max|delta| {d50:.3e}; "
           f"final max|delta| {d.max():.3e} rms {np.sqrt((d ** 2).mean()):.3e}, {(d > 1e-4).sum()} of {d.size} pixels above 1e-4")
-    assert d50 < 1e-4 and np.sqrt((d ** 2).mean()) < 3e-5 and d.max() < 2e-3
+    assert d50 < TOL
+    # two executions of OUR arithmetic in different summation orders are held to the rule a HIP run is held to against the reference
+    _accept_final_image("split-K plan vs unsplit plan", float(d.max()), float(np.sqrt((d ** 2).mean())), int((d > TOL).sum()), d.size,
+                        reference_self_consistency())
     small.close()
 
 
