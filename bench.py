@@ -36,7 +36,8 @@ Extra objects on the JSON line:
                 v_mfma_f32_32x32x2_f32 -- the arithmetic `north_star` names) and CDDPM_CONV=x6 (exact 3-term bf16 split),
                 each in a child process (the family is chosen once per process); `h3_nb2`: the default family with the opt-in
                 256-cout-workgroup plan on every step (cddpm_set_accumulation_switch(0): faster, two-level accumulation).
-  config.small_batch the reference's real call shape (DDPM_2D.py:193: 4 slices per volume): B = 4, 50 reverse steps.
+  config.small_batch the reference's real call shape (DDPM_2D.py:193: 4 slices per volume): B = 4, 50 reverse steps;
+                config.small_batch_two_streams: the same as two half-batches on two streams (engine.reverse_two_streams, identical bits).
   config.training_step  BASELINE config 5's per-GPU share (16 x 1 x 128 x 128, noise-prediction MSE, Adam; the context encoder trained jointly,
                 as the reference does): ms per optimisation step on the HIP operators (training.py), 1 warm-up + 3 timed steps.
                 Carries `precision`, a `training_roofline` object per MFMA operator class (weight-gradient GEMMs; forward + input-gradient
@@ -480,6 +481,22 @@ def main():
     if rank == 0 and world == 1 and not args.no_alt:
         # the reference's real call shape: 4 slices per volume (DDPM_2D.py:193)
         out["config"]["small_batch"] = short_rate(torch, dev, 4, S, n_rev=50, warm=10)
+        try:        # the same call as two half-batches on two streams / two handles (engine.reverse_two_streams: identical bits)
+            ea, synth_ = make_engine(torch, dev, 4, S)
+            eb, _ = make_engine(torch, dev, 4, S)
+            c4 = torch.from_numpy(synth_.synth_cond(1, 0, 4)).to(dev)
+            x4 = ea.noise_fill(4, S, S, seed=2, stream_id=synth_.STREAM_XT, slice0=0)
+            ea.reverse_two_streams(eb, x4, c4, 10, seed=3)
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            ea.reverse_two_streams(eb, x4, c4, 50, seed=3)
+            torch.cuda.synchronize(dev)
+            ms = (time.perf_counter() - t0) * 1e3 / 50
+            out["config"]["small_batch_two_streams"] = {"batch": 4, "reverse_steps_timed": 50, "ms_per_reverse_step": ms,
+                                                        "slices_per_s": 4 / (T_TOTAL * ms * 1e-3)}
+            ea.close(); eb.close()
+        except Exception as e:
+            out["config"]["small_batch_two_streams"] = {"error": repr(e)}
         # the strict-fp32 and exact-bf16-split families on the same workload, one child process each
         alts = {}
         for fam in ("f32", "x6", "h3_nb2"):

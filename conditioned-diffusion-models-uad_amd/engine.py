@@ -184,6 +184,39 @@ class CddpmEngine:
         self._check_finite(x, "cddpm_reverse")
         return x
 
+    def reverse_two_streams(self, twin: "CddpmEngine", x_T: torch.Tensor, cond: Optional[torch.Tensor], t_start: int, *, seed: int = 0,
+                            slice0: int = 0) -> torch.Tensor:
+        """`reverse` for a SMALL batch as two half-batches on two streams: this engine runs the first half, `twin` (an engine created
+        with the same geometry and loaded with the same weights and schedule: the same kernel plan, hence the same bits) the second,
+        enqueued step by step in alternation, so that one half's small launches (GroupNorm finalizes, split-K combines, attention, the
+        posterior step) run behind the other half's convolutions. Same result as `reverse`, bit for bit (slices are independent; noise is
+        keyed by the global slice index); measured +4.3 % at B = 4, +2.4 % at B = 2, nothing from B = 8 on (tools/dual_stream_reverse.py).
+        Device Philox noise only."""
+        x = _check_dev(x_T, "x_T", self.device).clone()
+        B, c, H, W = x.shape
+        if c != 1 or B < 2:
+            raise RuntimeError("reverse_two_streams needs x_T [B,1,H,W] with B >= 2")
+        if (twin.max_batch, twin.max_h, twin.max_w, twin.timesteps) != (self.max_batch, self.max_h, self.max_w, self.timesteps):
+            raise RuntimeError("the twin engine must be created with the same geometry (the kernel plan is part of a slice's bits)")
+        h = (B + 1) // 2
+        main = torch.cuda.current_stream(self.device)
+        if getattr(self, "_two_streams", None) is None:
+            self._two_streams = (torch.cuda.Stream(self.device), torch.cuda.Stream(self.device))
+        halves = [(self, self._two_streams[0], x[:h], None if cond is None else cond[:h].contiguous(), slice0),
+                  (twin, self._two_streams[1], x[h:], None if cond is None else cond[h:].contiguous(), slice0 + h)]
+        for e, s, xs, cs, _s0 in halves:
+            s.wait_stream(main)
+            with torch.cuda.stream(s):
+                e.prepare_cond(cs, xs.shape[0])
+        for t in range(t_start - 1, -1, -1):
+            for e, s, xs, _cs, s0 in halves:
+                with torch.cuda.stream(s):
+                    e.reverse_range_(xs, t, t, seed=seed, slice0=s0)
+        for _e, s, _xs, _cs, _s0 in halves:
+            main.wait_stream(s)
+        self._check_finite(x, "reverse_two_streams")
+        return x
+
     def reverse_range_(self, x: torch.Tensor, t_hi: int, t_lo: int, *, noise: Optional[torch.Tensor] = None, seed: int = 0,
                        slice0: int = 0) -> torch.Tensor:
         """steps t_hi .. t_lo of the chain IN PLACE on a device tensor (context from the last prepare_cond); the result is

@@ -299,3 +299,17 @@ def test_ragged_geometries_vs_oracle(engine_factory, synth, oracle, sd_torch, B,
         out = eng.reverse(x.cuda(), cond.cuda(), 3, noise=noise.cuda()).cpu().numpy()
         assert np.abs(out - loop_ref).max() < TOL, (mb, mh, mw)
         eng.close()
+
+
+def test_reverse_on_two_streams_is_bit_identical(engine_factory, synth):
+    """engine.reverse_two_streams: a small batch as two half-batches on two handles / two streams, step by step in alternation (one
+    half's small launches hide behind the other half's convolutions) -- the same bits as the one-stream reverse, odd batch included"""
+    T, steps, H, W = 1000, 12, 32, 32
+    a = engine_factory(timesteps=T, max_batch=4, max_h=H, max_w=W)
+    b = engine_factory(timesteps=T, max_batch=4, max_h=H, max_w=W)
+    for B in (4, 3):
+        x = torch.from_numpy(synth.noise_xT(2, 5, B, H, W)).cuda()
+        cond = torch.from_numpy(synth.synth_cond(1, 5, B)).cuda()
+        one = a.reverse(x, cond, steps, seed=3, slice0=5)
+        two = a.reverse_two_streams(b, x, cond, steps, seed=3, slice0=5)
+        assert torch.equal(one, two), B
