@@ -50,6 +50,7 @@ def test_bench_complete_reconstruction_small():
     assert out["steps"] == 20 and cfg["reverse_steps_timed"] == 1000 and cfg["complete_reconstructions_timed"] == 1.0
     assert cfg["finite"] is True and cfg["reconstruction_in_unit_range"] is True
     assert cfg["small_batch"]["batch"] == 4 and cfg["small_batch"]["slices_per_s"] > 0
+    assert cfg["small_batch_two_streams"].get("slices_per_s", 0) > 0, cfg["small_batch_two_streams"]
     assert set(cfg["alt_paths"]) == {"f32", "x6", "h3_nb2"}
     for fam, v in cfg["alt_paths"].items():
         assert v.get("conv_family") == fam and v["slices_per_s"] > 0 and v["finite"] is True, (fam, v)
