@@ -280,7 +280,12 @@ def residual_workload(args, torch, dev, rank, world, dist, result_fd):
         dist.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
-    res = sharding.residual_maps_sharded(eng, N, S, S, **kw)
+
+    def progress(s0, cnt):        # a chunk of 64 full-length reconstructions takes ~45 s: one stderr line per chunk from rank 0
+        if rank == 0:
+            print(f"[residual] rank 0: slices {s0} .. {s0 + cnt - 1} of its block, {time.perf_counter() - t0:.0f} s", file=sys.stderr, flush=True)
+
+    res = sharding.residual_maps_sharded(eng, N, S, S, progress=progress, **kw)
     torch.cuda.synchronize(dev)
     if dist is not None:
         dist.barrier()

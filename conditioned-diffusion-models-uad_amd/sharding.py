@@ -67,13 +67,16 @@ def reconstruct_sharded(n_slices: int, shape_hw: Tuple[int, int], reconstruct_ch
 
 
 def residual_maps_sharded(engine, n_slices: int, H: int, W: int, *, seed_inputs: int, seed_cond: int, seed_noise: int,
-                          t_start: int, chunk: int = 64, gather: str = "all") -> Optional[torch.Tensor]:
-    """BASELINE config 4: synthetic slices x in (0,1), reconstruct each from noise, gather |x - reco|."""
+                          t_start: int, chunk: int = 64, gather: str = "all", progress=None) -> Optional[torch.Tensor]:
+    """BASELINE config 4: synthetic slices x in (0,1), reconstruct each from noise, gather |x - reco|.
+    progress: optional callable(slice0, count) called before every chunk (a long run's sign of life)."""
     from . import synth
 
     dev = engine.device
 
     def run(slice0: int, count: int) -> torch.Tensor:
+        if progress is not None:
+            progress(slice0, count)
         x = torch.from_numpy(synth.synth_slices(seed_inputs, slice0, count, H, W)).to(dev)
         cond = torch.from_numpy(synth.synth_cond(seed_cond, slice0, count)).to(dev)
         x_T = engine.noise_fill(count, H, W, seed=seed_noise, stream_id=synth.STREAM_XT, slice0=slice0)
