@@ -491,7 +491,7 @@ class UNetTrainer:
         batched = self._lead if self.emb_rows else ()
         return min((o for k, o in self._goff.items() if k.startswith(prefix) and k not in batched), default=self.gflat.numel())
 
-    def backward(self, dout: torch.Tensor, buckets: Optional["GradBuckets"] = None) -> Dict[str, torch.Tensor]:
+    def backward(self, dout: torch.Tensor, buckets: Optional["GradBuckets"] = None, join: bool = True) -> Dict[str, torch.Tensor]:
         """fills `g` (views of `gflat`) from dout = grad_scale * dL/d(model output); returns `g`. buckets: the gradient exchange, told after
         every operator how much of the buffer's tail is final (GradBuckets: all-reduce overlapped with the rest of the backward pass)"""
         p, sv, g = self.p, self.saved, self.g
@@ -586,7 +586,8 @@ class UNetTrainer:
             det, self.dcond = demb, None
         dy1 = self.linear_bwd(sv["y1"], "time_embed.2", det, True)
         self.linear_bwd(sv["temb"], "time_embed.0", dy1, False)
-        self.join_side()         # every gradient of the buffer is in place for whoever reads it next
+        if join:                 # every gradient of the buffer is in place for whoever reads it next (join=False: the caller joins later --
+            self.join_side()     # the step lets the last weight gradients run beside the encoder's backward chain)
         self.saved = None
         return g
 
@@ -780,11 +781,12 @@ def training_step(trainer: UNetTrainer, x01: torch.Tensor, cond: Optional[torch.
     # the gradient exchange runs bucket by bucket BEHIND the backward pass: a bucket's all-reduce is issued as soon as its slice of the
     # flat buffer is final and overlaps the backward operators that follow (and, for the UNet's last buckets, the encoder's backward)
     buckets = GradBuckets(trainer.gflat, enabled=all_reduce)
-    trainer.backward(dout, buckets)
+    trainer.backward(dout, buckets, join=(encoder is None))
     enc_buckets = None
     if encoder is not None:
         enc_buckets = GradBuckets(encoder.gflat, enabled=all_reduce)
-        encoder.backward(trainer.dcond, enc_buckets)       # carries the same loss scale
+        encoder.backward(trainer.dcond, enc_buckets)       # carries the same loss scale; joins the side stream at its end
+    trainer.join_side()
     world = buckets.finish()
     if enc_buckets is not None:
         enc_buckets.finish()
